@@ -1,0 +1,181 @@
+/*
+ * cgpt.h -- C-ABI of libcgpt.so: the MI355X-native randomized-smoothing certify/predict hot path.
+ *
+ * The reference (leodesouza/certifiedGPT) has no FFI: its hot path is the Python class
+ * `Smooth` (randomized_smoothing/smoothing.py:13-117) calling a PyTorch base classifier
+ * (MiniGPT4.encode_img, graphs/models/minigpt4/models/minigpt4.py:121-149, built from
+ * eva_vit.py / Qformer.py).  Each entry point below names the reference interface it replaces.
+ * A maintainer binds them with ctypes; certifiedgpt_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (streams are passed as void* = hipStream_t,
+ *     0 = the null stream; PyTorch-ROCm's torch.cuda.current_stream().cuda_stream is accepted as is).
+ *   - every function returns cgpt_status (0 = ok).  Nothing throws across the ABI;
+ *     cgpt_last_error() returns a thread-local message for the last failing call.
+ *   - the caller owns every buffer it passes.  `*_dev` pointers are device (HBM) pointers,
+ *     `*_host` pointers are host pointers.
+ *   - a handle is bound to one device and is NOT thread-safe: one handle per process per GPU.
+ *     All device work is enqueued on the caller's stream; the only host syncs are inside
+ *     cgpt_load_weight/cgpt_get_weight (host<->device copies) and where documented.
+ *   - there is no CPU fallback: device entry points fail with CGPT_ERR_NO_DEVICE without a GPU.
+ */
+#ifndef CGPT_H
+#define CGPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int cgpt_status;
+enum {
+    CGPT_OK = 0,
+    CGPT_ERR_INVALID = 1,     /* bad argument / shape mismatch                         */
+    CGPT_ERR_NO_DEVICE = 2,   /* no HIP device visible                                 */
+    CGPT_ERR_HIP = 3,         /* a HIP runtime call failed (message in cgpt_last_error) */
+    CGPT_ERR_NOT_FOUND = 4,   /* unknown weight name                                   */
+    CGPT_ERR_STATE = 5        /* weights not loaded / wrong mode                       */
+};
+
+#define CGPT_ABSTAIN (-1)     /* Smooth.ABSTAIN, smoothing.py:17 */
+
+/* What the base classifier computes after the noise is added (smoothing.py:97 `base_classifier(batch + noise)`). */
+enum {
+    CGPT_MODE_VIT_HEAD = 0,   /* EVA-ViT-G forward_features (eva_vit.py:332-349) -> ln_vision (base_model.py:281-287)
+                                 on the CLS token -> build-side Linear(vit_dim -> num_classes) head.  BASELINE config 2. */
+    CGPT_MODE_ENCODE_IMG = 1  /* full MiniGPT4.encode_img (minigpt4.py:121-149): ViT -> ln_vision -> Q-Former
+                                 (Qformer.py:78-108,169-289,349-484) -> llama_proj, then a build-side head
+                                 Linear(proj_dim -> num_classes) on the mean of the query tokens.             */
+};
+
+typedef struct cgpt_config {
+    int32_t struct_size;      /* = sizeof(cgpt_config); guards ABI drift */
+    int32_t mode;             /* CGPT_MODE_*                                                       */
+    int32_t device;           /* HIP device ordinal                                                */
+    int32_t num_classes;      /* Smooth.num_classes, smoothing.py:19                               */
+    int32_t max_batch;        /* largest batch_size a call may use (sizes the HBM workspace)       */
+    /* EVA-ViT (create_eva_vit_g, eva_vit.py:425-438) */
+    int32_t img_size;         /* 224  */
+    int32_t patch_size;       /* 14   */
+    int32_t vit_dim;          /* 1408 */
+    int32_t vit_depth;        /* 39   */
+    int32_t vit_heads;        /* 16 (head_dim must be 88 or 64)                                    */
+    int32_t vit_mlp;          /* 6144 = int(1408 * 4.3637)                                         */
+    float   vit_ln_eps;       /* 1e-6 (eva_vit.py:436)                                             */
+    float   ln_vision_eps;    /* 1e-5 (nn.LayerNorm default, base_model.py:281)                    */
+    /* Q-Former (MiniGPT4.init_Qformer, minigpt4.py:90-119; BERT-base) -- ignored in CGPT_MODE_VIT_HEAD */
+    int32_t qf_layers;        /* 12   */
+    int32_t qf_dim;           /* 768  */
+    int32_t qf_heads;         /* 12 (head_dim must be 64)                                          */
+    int32_t qf_ffn;           /* 3072 */
+    int32_t qf_queries;       /* 32   */
+    int32_t qf_xattn_freq;    /* 2: cross-attention in layers 0,2,4,... (Qformer.py:386-395)       */
+    float   qf_ln_eps;        /* 1e-12 */
+    int32_t proj_dim;         /* 4096: llama_proj out features (minigpt4.py:76-78)                 */
+} cgpt_config;
+
+typedef struct cgpt_model* cgpt_handle;
+
+/* ---- life cycle (replaces: MiniGPT4.__init__/from_config device placement, minigpt4.py:29-199) ---- */
+cgpt_status cgpt_create(const cgpt_config* cfg, cgpt_handle* out);
+cgpt_status cgpt_destroy(cgpt_handle h);
+const char* cgpt_last_error(void);
+const char* cgpt_version(void);
+
+/* ---- weights (replaces: load_state_dict + convert_weights_to_fp16, eva_vit.py:407-422,454) ----
+ * Names follow the reference state_dict:  "visual_encoder.patch_embed.proj.weight", "visual_encoder.cls_token",
+ * "visual_encoder.pos_embed", "visual_encoder.blocks.<i>.{norm1,norm2}.{weight,bias}",
+ * "visual_encoder.blocks.<i>.attn.{qkv.weight,q_bias,v_bias,proj.weight,proj.bias}",
+ * "visual_encoder.blocks.<i>.mlp.{fc1,fc2}.{weight,bias}", "ln_vision.{weight,bias}", "query_tokens",
+ * "Qformer.bert.embeddings.LayerNorm.{weight,bias}",
+ * "Qformer.bert.encoder.layer.<i>.{attention,crossattention}.self.{query,key,value}.{weight,bias}",
+ * "Qformer.bert.encoder.layer.<i>.{attention,crossattention}.output.{dense,LayerNorm}.{weight,bias}",
+ * "Qformer.bert.encoder.layer.<i>.{intermediate_query,output_query}.dense.{weight,bias}",
+ * "Qformer.bert.encoder.layer.<i>.output_query.LayerNorm.{weight,bias}", "llama_proj.{weight,bias}",
+ * and the build-side "head.{weight,bias}".
+ * `data_host` is float32, contiguous, in the PyTorch shape; `numel` must match.  GEMM weights are stored
+ * in HBM as fp16 (the reference's precision contract on HIP: fp16 weights + fp16 autocast,
+ * eva_vit.py:407-414, base_model.py:132-142); LayerNorm / bias / pos_embed parameters stay fp32. */
+cgpt_status cgpt_load_weight(cgpt_handle h, const char* name, const float* data_host, int64_t numel);
+/* Copy a weight back as float32 (exactly the values the device computes with, i.e. after fp16 rounding). */
+cgpt_status cgpt_get_weight(cgpt_handle h, const char* name, float* out_host, int64_t numel);
+/* Number of elements of a named weight (for sizing cgpt_get_weight buffers); <0 if unknown. */
+int64_t     cgpt_weight_numel(cgpt_handle h, const char* name);
+/* Name of the i-th weight (NULL past the end) -- lets a binding enumerate the state_dict. */
+const char* cgpt_weight_name(cgpt_handle h, int32_t index);
+/* Fill every weight on the device following the reference's init law (eva_vit.py:295-323:
+ * trunc_normal(.02) Linear weights, zero biases, LN (1,0), proj/fc2 / sqrt(2*layer_id); Qformer.py:664-674:
+ * normal(0,.02); minigpt4.py:99-102) from a counter-based generator.  There is no checkpoint in the container. */
+cgpt_status cgpt_init_synthetic_weights(cgpt_handle h, uint64_t seed, void* stream);
+
+/* ---- the hot loop: Smooth._sample_noise (smoothing.py:81-99) ----
+ * For global sample indices s in [first_sample, first_sample + num): draw eps_s ~ N(0,1)^{3xHxW} from the
+ * counter-based stream keyed (noise_seed, s, element), run the base classifier on x + sigma*eps_s in
+ * batches of at most batch_size, take argmax(1) and ADD the votes into counts_dev[num_classes] (int64).
+ * counts_dev is NOT zeroed here (callers accumulate shards); no host sync.
+ * Sharding-aware through first_sample: counts are bit-identical for any partition of the index range. */
+cgpt_status cgpt_sample_counts(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num,
+                               int64_t batch_size, float sigma, uint64_t noise_seed,
+                               int64_t* counts_dev, void* stream);
+/* Same batches, but return the logits [num, num_classes] float32 instead of voting (parity tests; num <= max_batch). */
+cgpt_status cgpt_forward_logits(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num,
+                                float sigma, uint64_t noise_seed, float* logits_dev, void* stream);
+/* Run the classifier on caller-supplied images [num,3,H,W] float32 (no noise) -> logits [num,num_classes]. */
+cgpt_status cgpt_classify(cgpt_handle h, const float* images_dev, int64_t num, float* logits_dev, void* stream);
+/* Intermediate activations of the last cgpt_forward_logits / cgpt_classify call, as float32, for parity tests:
+ * what = "vit_out"   [num, T, vit_dim]   (VisionTransformer.forward_features output, eva_vit.py:349)
+ *        "ln_vision" [num, T, vit_dim]   (CGPT_MODE_ENCODE_IMG only; minigpt4.py:129)
+ *        "qformer"   [num, Q, qf_dim]    (query_output.last_hidden_state, minigpt4.py:134-139)
+ *        "llama"     [num, Q, proj_dim]  (inputs_llama, minigpt4.py:141)                                      */
+cgpt_status cgpt_get_activation(cgpt_handle h, const char* what, float* out_dev, int64_t numel, void* stream);
+
+/* ---- pieces of the loop, for callers whose base classifier is not this library's
+ *      (e.g. full MiniGPT-4 with a Vicuna decode on PyTorch-ROCm, minigpt_base.py:374-448) ---- */
+/* smoothing.py:95-96: out[b] = x + sigma * eps_{first_sample+b}; out_dev is [num,3,H,W] float32.  Handle-free. */
+cgpt_status cgpt_noise_batch(const float* x_dev, int64_t chw, int64_t first_sample, int64_t num, float sigma,
+                             uint64_t noise_seed, float* out_dev, void* stream);
+/* smoothing.py:97-98,101-105: counts_dev[argmax(logits[b,:])] += 1 for b < num (first max index on ties). */
+cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes, int64_t* counts_dev, void* stream);
+
+/* ---- statistics: pure host functions, float64, no device needed ----
+ * Smooth.certify lines 46-56 given the two histograms (smoothing.py:44,48). */
+cgpt_status cgpt_certify_from_counts(const int64_t* counts_selection, const int64_t* counts_estimation,
+                                     int32_t num_classes, int64_t n, double alpha, double sigma,
+                                     int32_t* label_out, double* radius_out);
+/* Smooth.predict lines 73-79 given the histogram (smoothing.py:72). */
+cgpt_status cgpt_predict_from_counts(const int64_t* counts, int32_t num_classes, double alpha, int32_t* label_out);
+/* Smooth._lower_confidence_bound (smoothing.py:107-117) == statsmodels proportion_confint(NA,N,2*alpha,"beta")[0]. */
+double cgpt_lower_confidence_bound(int64_t NA, int64_t N, double alpha);
+/* scipy.stats.binom_test(x, n, p) two-sided (scipy 1.7 algorithm; call site smoothing.py:76). */
+double cgpt_binom_test(int64_t x, int64_t n, double p);
+/* scipy.stats.norm.ppf (call site smoothing.py:55). */
+double cgpt_norm_ppf(double p);
+
+/* ---- measurement hooks (bench.py roofline) ----
+ * When enabled, every GEMM launch is bracketed by HIP events on the launch stream; totals are read back with
+ * cgpt_profile_read (which synchronises those events).  kind: 0 = all GEMMs, 1 = fc1 (GELU epilogue) GEMMs only. */
+cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on);
+cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
+
+/* ---- raw kernels exported for unit tests and reuse (all fp16 operands are IEEE binary16) ----
+ * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) ; A row stride lda, W row stride ldw (elements), fp32 accumulate.
+ * Requirements: M%256==0 is NOT required, but A must be readable for ceil(M/128)*128 rows;
+ * K%64==0, N%128==0 (pad with zeros; the library's own buffers always are).  out is fp32 [M,ldc]. */
+cgpt_status cgpt_gemm_f16(const void* A_dev, int64_t lda, const void* W_dev, int64_t ldw, const float* bias_dev,
+                          float* C_dev, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+/* softmax(scale * Q K^T) V per (batch, head): Q [B,Tq,ldq] K,V [B,Tk,ldkv] fp16 with head h at column h*head_dim;
+ * O [B,Tq,ldo] fp16.  head_dim in {64, 88}.  (eva_vit.py:133-150; Qformer.py:244-264 with zero masks) */
+cgpt_status cgpt_attention_f16(const void* Q_dev, int64_t ldq, const void* K_dev, const void* V_dev, int64_t ldkv,
+                               void* O_dev, int64_t ldo, int32_t B, int32_t heads, int32_t head_dim,
+                               int32_t Tq, int32_t Tk, float scale, void* stream);
+/* y = LayerNorm(x) * gamma + beta over the last dim D (fp32 statistics), x fp32 [rows, ldx] -> y fp16 [rows, ldy]
+ * (and optionally y32 fp32 [rows, ldy32] when y32_dev != NULL).  (eva_vit.py:162,168; base_model.py:281-287) */
+cgpt_status cgpt_layernorm(const float* x_dev, int64_t ldx, const float* gamma_dev, const float* beta_dev, float eps,
+                           void* y_dev, int64_t ldy, float* y32_dev, int64_t ldy32, int64_t rows, int32_t D,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGPT_H */
