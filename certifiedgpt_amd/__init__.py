@@ -1,0 +1,10 @@
+"""certifiedgpt_amd -- MI355X-native randomized-smoothing certify/predict hot path.
+
+Drop-in for the path `Smooth.certify` / `Smooth.predict` of leodesouza/certifiedGPT
+(randomized_smoothing/smoothing.py) over MiniGPT-4's image encoder; see DESIGN.md / INTEGRATION.md.
+"""
+from ._lib import CgptError, lib, LIB_PATH  # noqa: F401
+from .smoothing import Smooth, shard_range  # noqa: F401
+from .classifier import HipClassifier, noise_batch, vote  # noqa: F401
+
+__all__ = ["Smooth", "HipClassifier", "noise_batch", "vote", "shard_range", "CgptError", "lib", "LIB_PATH"]

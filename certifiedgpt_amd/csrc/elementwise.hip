@@ -1,0 +1,319 @@
+// elementwise.hip -- the HBM-bound kernels of the hot path: Gaussian perturbation fused with the patch-embed
+// im2col, LayerNorm, CLS/pos rows, query-token broadcast, mean pool, argmax + vote histogram, weight fills/casts.
+//
+// Reference ops replaced: smoothing.py:95-98,101-105 (repeat + randn*sigma; argmax(1); _count_arr),
+// eva_vit.py:162,168 + base_model.py:281-287 (LayerNorm), eva_vit.py:337-340 (CLS concat + pos_embed),
+// minigpt4.py:132 (query_tokens.expand), Qformer.py:106 (embeddings LayerNorm).
+#include "kernels.h"
+#include "philox.h"
+
+namespace cgpt {
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row; the row lives in registers (NCH float2 per lane) between the mean, the centred variance
+// and the normalise pass, so x is read from HBM exactly once.  Requires D even and D <= NCH*128.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        half_t* __restrict__ y16, int64_t ldy16,
+                                                        float* __restrict__ y32, int64_t ldy32, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float2 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 128 + lane * 2;
+        v[c] = (col < D) ? *reinterpret_cast<const float2*>(xr + col) : make_float2(0.f, 0.f);
+        s += v[c].x + v[c].y;
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 128 + lane * 2;
+        if (col < D) {
+            const float dx = v[c].x - mean, dy = v[c].y - mean;
+            q += dx * dx + dy * dy;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 128 + lane * 2;
+        if (col < D) {
+            const float2 gm = *reinterpret_cast<const float2*>(gamma + col);
+            const float2 bt = *reinterpret_cast<const float2*>(beta + col);
+            const float a = (v[c].x - mean) * rstd * gm.x + bt.x;
+            const float b = (v[c].y - mean) * rstd * gm.y + bt.y;
+            if (y16) {
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<f16x2*>(y16 + row * ldy16 + col) = f16x2{(half_t)a, (half_t)b};
+            }
+            if (y32) *reinterpret_cast<float2*>(y32 + row * ldy32 + col) = make_float2(a, b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ noise (+ im2col of the patch embedding)
+// Destination of pixel (c, y, x) in the im2col matrix: row = b*P + (y/ps)*(img/ps) + x/ps,
+// column = c*ps*ps + (y%ps)*ps + x%ps   (= the flattening of Conv2d weight [D,3,ps,ps], eva_vit.py:202).
+template <bool NOISE>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ src, int img, int ps,
+                                                     int64_t first_sample, int nb, float sigma, uint64_t seed,
+                                                     half_t* __restrict__ A, int64_t lda) {
+    const int groups = 3 * img * img / 4;                       // 4 consecutive pixels of one image row
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)groups * nb) return;
+    const int b = (int)(gid / groups), grp = (int)(gid - (int64_t)b * groups);
+    const int e = grp * 4;
+    const int c = e / (img * img), rem = e - c * img * img;
+    const int y = rem / img, x0 = rem - y * img;
+    // NOISE: src is the single clean image x[3,img,img]; else src is the batch [nb,3,img,img]
+    float4 px = *reinterpret_cast<const float4*>(src + (NOISE ? 0 : (int64_t)b * 3 * img * img) + e);
+    if (NOISE) {
+        const float4 z = normal4(seed, (uint64_t)(first_sample + b), (uint32_t)grp, 0u);
+        px.x += sigma * z.x; px.y += sigma * z.y; px.z += sigma * z.z; px.w += sigma * z.w;
+    }
+    const int pw = img / ps;
+    const int py = y / ps, iy = y - py * ps;
+    const float vals[4] = {px.x, px.y, px.z, px.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + k;
+        const int pxi = x / ps, ix = x - pxi * ps;
+        const int64_t row = (int64_t)b * pw * pw + py * pw + pxi;
+        A[row * lda + c * ps * ps + iy * ps + ix] = (half_t)vals[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void noise_batch_kernel(const float* __restrict__ x, int64_t chw,
+                                                          int64_t first_sample, int64_t num, float sigma,
+                                                          uint64_t seed, float* __restrict__ out) {
+    const int64_t groups = (chw + 3) / 4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= groups * num) return;
+    const int64_t b = gid / groups, grp = gid - b * groups;
+    const float4 z = normal4(seed, (uint64_t)(first_sample + b), (uint32_t)grp, 0u);
+    const float zz[4] = {z.x, z.y, z.z, z.w};
+    const int64_t e = grp * 4;
+    if (e + 3 < chw && (chw & 3) == 0) {
+        const float4 px = *reinterpret_cast<const float4*>(x + e);
+        *reinterpret_cast<float4*>(out + b * chw + e) =
+            make_float4(px.x + sigma * zz[0], px.y + sigma * zz[1], px.z + sigma * zz[2], px.w + sigma * zz[3]);
+    } else {
+        for (int k = 0; k < 4 && e + k < chw; ++k) out[b * chw + e + k] = x[e + k] + sigma * zz[k];
+    }
+}
+
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                float* __restrict__ resid, int64_t ld, int T, int nb, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb * D) return;
+    const int b = i / D, n = i - b * D;
+    resid[(int64_t)b * T * ld + n] = cls[n] + pos[n];
+}
+
+__global__ void broadcast_rows_kernel(const float* __restrict__ src, int rows, int D, int nb,
+                                      float* __restrict__ dst32, int64_t ld32, half_t* __restrict__ dst16, int64_t ld16) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nb * rows * D) return;
+    const int n = (int)(i % D);
+    const int64_t br = i / D;                     // b*rows + r
+    const float v = src[(br % rows) * D + n];
+    dst32[br * ld32 + n] = v;
+    dst16[br * ld16 + n] = (half_t)v;
+}
+
+__global__ void mean_rows_kernel(const float* __restrict__ src, int64_t lds, int rows, int D, int nb,
+                                 half_t* __restrict__ dst16, int64_t ld16) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb * D) return;
+    const int b = i / D, n = i - b * D;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += src[((int64_t)b * rows + r) * lds + n];
+    dst16[(int64_t)b * ld16 + n] = (half_t)(s / (float)rows);
+}
+
+// ------------------------------------------------------------------------------- argmax + vote histogram
+// One wave per sample.  Each lane scans classes lane, lane+64, ... keeping the first maximum (strict >),
+// then a 6-step xor-shuffle butterfly keeps (larger value, then smaller index): ndarray/tensor argmax semantics
+// "first maximal index" (smoothing.py:97).  Lane 0 adds the vote with one 64-bit atomic (smoothing.py:98,101-105).
+__global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ logits, int64_t ld, int64_t num, int K,
+                                                   unsigned long long* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= num) return;
+    const float* row = logits + s * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+        const float v = row[k];
+        if (v > best || bi == 0x7fffffff) { best = v; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) atomicAdd(counts + bi, 1ull);
+}
+
+// ------------------------------------------------------------------------------------- fills and casts
+__global__ void fill_normal_kernel(void* dst, int is_f16, int64_t rows, int64_t cols, int64_t ld, float mean,
+                                   float stdv, uint64_t seed, uint64_t tensor_id) {
+    const int64_t groups = (rows * cols + 3) / 4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= groups) return;
+    const float4 z = normal4(seed, tensor_id, (uint32_t)gid, 1u + (uint32_t)(gid >> 32));
+    const float zz[4] = {z.x, z.y, z.z, z.w};
+    for (int k = 0; k < 4; ++k) {
+        const int64_t e = gid * 4 + k;
+        if (e >= rows * cols) break;
+        const int64_t r = e / cols, c = e - r * cols;
+        const float v = mean + stdv * zz[k];
+        if (is_f16) reinterpret_cast<half_t*>(dst)[r * ld + c] = (half_t)v;
+        else reinterpret_cast<float*>(dst)[r * ld + c] = v;
+    }
+}
+
+__global__ void fill_const_kernel(float* dst, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
+__global__ void f32_to_f16_kernel(const float* src, int64_t lds, half_t* dst, int64_t ldd, int64_t rows, int64_t cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols, c = i - r * cols;
+    dst[r * ldd + c] = (half_t)src[r * lds + c];
+}
+
+__global__ void f16_to_f32_kernel(const half_t* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols, c = i - r * cols;
+    dst[r * ldd + c] = (float)src[r * lds + c];
+}
+
+inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                            half_t* y16, int64_t ldy16, float* y32, int64_t ldy32, int64_t rows, int D,
+                            hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    if (D <= 0 || (D & 1) || D > 32 * 128 || (ldx & 1) || (ldy16 & 1) || (ldy32 & 1)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define CGPT_LN(NCH) hipLaunchKernelGGL(layernorm_kernel<NCH>, grid, block, 0, stream, x, ldx, gamma, beta, eps, \
+                                        y16, ldy16, y32, ldy32, rows, D)
+    if (D <= 2 * 128) CGPT_LN(2);
+    else if (D <= 6 * 128) CGPT_LN(6);
+    else if (D <= 11 * 128) CGPT_LN(11);
+    else if (D <= 16 * 128) CGPT_LN(16);
+    else CGPT_LN(32);
+#undef CGPT_LN
+    return hipGetLastError();
+}
+
+hipError_t launch_noise_im2col(const float* x, int img, int ps, int64_t first_sample, int nb, float sigma,
+                               uint64_t seed, half_t* A, int64_t lda, hipStream_t stream) {
+    if (nb <= 0) return hipSuccess;
+    if ((img & 3) || (img % ps)) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)nb * 3 * img * img / 4;
+    hipLaunchKernelGGL(im2col_kernel<true>, dim3(blocks_for(n)), dim3(256), 0, stream, x, img, ps, first_sample, nb,
+                       sigma, seed, A, lda);
+    return hipGetLastError();
+}
+
+hipError_t launch_im2col(const float* images, int img, int ps, int nb, half_t* A, int64_t lda, hipStream_t stream) {
+    if (nb <= 0) return hipSuccess;
+    if ((img & 3) || (img % ps)) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)nb * 3 * img * img / 4;
+    hipLaunchKernelGGL(im2col_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, stream, images, img, ps, (int64_t)0, nb,
+                       0.0f, (uint64_t)0, A, lda);
+    return hipGetLastError();
+}
+
+hipError_t launch_noise_batch(const float* x, int64_t chw, int64_t first_sample, int64_t num, float sigma,
+                              uint64_t seed, float* out, hipStream_t stream) {
+    if (num <= 0) return hipSuccess;
+    const int64_t n = ((chw + 3) / 4) * num;
+    hipLaunchKernelGGL(noise_batch_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, x, chw, first_sample, num, sigma,
+                       seed, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_cls_rows(const float* cls, const float* pos, float* resid, int64_t ld, int T, int nb, int D,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(blocks_for((int64_t)nb * D)), dim3(256), 0, stream, cls, pos, resid, ld, T,
+                       nb, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_broadcast_rows(const float* src, int rows, int D, int nb, float* dst32, int64_t ld32, half_t* dst16,
+                                 int64_t ld16, hipStream_t stream) {
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3(blocks_for((int64_t)nb * rows * D)), dim3(256), 0, stream, src, rows,
+                       D, nb, dst32, ld32, dst16, ld16);
+    return hipGetLastError();
+}
+
+hipError_t launch_mean_rows(const float* src, int64_t lds, int rows, int D, int nb, half_t* dst16, int64_t ld16,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(blocks_for((int64_t)nb * D)), dim3(256), 0, stream, src, lds, rows, D, nb,
+                       dst16, ld16);
+    return hipGetLastError();
+}
+
+hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int64_t* counts, hipStream_t stream) {
+    if (num <= 0) return hipSuccess;
+    hipLaunchKernelGGL(vote_kernel, dim3((unsigned)((num + 3) / 4)), dim3(256), 0, stream, logits, ld, num, K,
+                       reinterpret_cast<unsigned long long*>(counts));
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_normal(void* dst, int is_f16, int64_t rows, int64_t cols, int64_t ld, float mean, float stdv,
+                              uint64_t seed, uint64_t tensor_id, hipStream_t stream) {
+    const int64_t groups = (rows * cols + 3) / 4;
+    if (groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_normal_kernel, dim3(blocks_for(groups)), dim3(256), 0, stream, dst, is_f16, rows, cols, ld,
+                       mean, stdv, seed, tensor_id);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_const(float* dst, int64_t n, float v, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_const_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, dst, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_to_f16(const float* src, int64_t lds, half_t* dst, int64_t ldd, int64_t rows, int64_t cols,
+                             hipStream_t stream) {
+    if (rows * cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(blocks_for(rows * cols)), dim3(256), 0, stream, src, lds, dst, ldd, rows,
+                       cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_f16_to_f32(const half_t* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols,
+                             hipStream_t stream) {
+    if (rows * cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3(blocks_for(rows * cols)), dim3(256), 0, stream, src, lds, dst, ldd, rows,
+                       cols);
+    return hipGetLastError();
+}
+
+}  // namespace cgpt

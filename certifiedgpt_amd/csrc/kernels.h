@@ -1,0 +1,83 @@
+// kernels.h -- host-callable launchers of the HIP kernels (all enqueue on `stream`, no host sync).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cgpt {
+
+typedef _Float16 half_t;
+
+// ---------------------------------------------------------------------------------------------- GEMM
+// C = A[M,K] * W[N,K]^T with a fused epilogue.  A/W are fp16, K contiguous.  Requirements (the library's
+// own buffers satisfy them): K % 64 == 0; A readable for round_up(M,128) rows; W readable for
+// round_up(N,128) rows; pad K-columns of A and W hold zeros.
+enum GemmEpilogue {
+    EPI_F16 = 0,        // out_f16[m,n] = acc + bias[n]
+    EPI_F16_GELU = 1,   // out_f16[m,n] = gelu_erf(acc + bias[n])                        (eva_vit.py:60-61)
+    EPI_F32 = 2,        // out_f32[m,n] = acc + bias[n]
+    EPI_RESID = 3,      // out_f32[m,n] = aux_f32[m,n] + acc + bias[n]  (aux may alias out: x = x + f(x), eva_vit.py:180-181)
+    EPI_PATCH = 4       // patch-embed: row m=(b,p) -> out_f32[b*(P+1)+1+p, n] = acc + bias[n] + aux[(1+p), n]  (eva_vit.py:209,337-340)
+};
+struct GemmParams {
+    const half_t* A; int64_t lda;
+    const half_t* W; int64_t ldw;
+    const float* bias;            // [N] or nullptr
+    void* out; int64_t ldo;
+    const float* aux; int64_t ldaux;
+    int M, N, K;
+    int patches;                  // EPI_PATCH: P (patches per image)
+};
+hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------- attention
+// O[b,q,h*hd + d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d]   (eva_vit.py:133-150,
+// Qformer.py:244-264 with all-zero masks).  head_dim 88 or 64.  Row strides in elements.
+struct AttnParams {
+    const half_t* Q; int64_t ldq; int64_t q_batch_stride;
+    const half_t* K; int64_t ldk;
+    const half_t* V; int64_t ldv; int64_t kv_batch_stride;
+    half_t* O; int64_t ldo; int64_t o_batch_stride;
+    int B, heads, head_dim, Tq, Tk;
+    float scale;
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+
+// --------------------------------------------------------------------------------------- LayerNorm
+// y = (x - mean) / sqrt(var + eps) * gamma + beta over D, fp32 statistics (base_model.py:281-287).
+// Input row r is x + r*ldx; outputs y16 (fp16, may be null) and y32 (fp32, may be null).
+hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                            half_t* y16, int64_t ldy16, float* y32, int64_t ldy32, int64_t rows, int D,
+                            hipStream_t stream);
+
+// ------------------------------------------------------------------------------ noise / im2col / misc
+// smoothing.py:95-96 fused with the patch-embed im2col (eva_vit.py:202,209): for sample s = first_sample + b,
+// patch p, element e=(c,i,j):  A[(b*P + p), e] = fp16(x[c, py*ps+i, px*ps+j] + sigma * eps_s[c, .., ..]).
+hipError_t launch_noise_im2col(const float* x, int img, int ps, int64_t first_sample, int nb, float sigma,
+                               uint64_t seed, half_t* A, int64_t lda, hipStream_t stream);
+// Same im2col for caller-supplied images [nb,3,img,img] (no noise).
+hipError_t launch_im2col(const float* images, int img, int ps, int nb, half_t* A, int64_t lda, hipStream_t stream);
+// out[b, :] = x + sigma * eps_{first_sample + b}   (fp32 images; handle-free C-ABI cgpt_noise_batch)
+hipError_t launch_noise_batch(const float* x, int64_t chw, int64_t first_sample, int64_t num, float sigma,
+                              uint64_t seed, float* out, hipStream_t stream);
+// resid[b*T + 0, :] = cls + pos[0, :]   (eva_vit.py:337-340, CLS row)
+hipError_t launch_cls_rows(const float* cls, const float* pos, float* resid, int64_t ld, int T, int nb, int D,
+                           hipStream_t stream);
+// dst32[b*rows + r, :] = src32[r, :], dst16 likewise (query_tokens.expand, minigpt4.py:132)
+hipError_t launch_broadcast_rows(const float* src, int rows, int D, int nb, float* dst32, int64_t ld32,
+                                 half_t* dst16, int64_t ld16, hipStream_t stream);
+// dst16[b, :] = mean_r src32[b*rows + r, :]
+hipError_t launch_mean_rows(const float* src, int64_t lds, int rows, int D, int nb, half_t* dst16, int64_t ld16,
+                            hipStream_t stream);
+// smoothing.py:97-98,101-105: counts[argmax_k logits[b,k]] += 1 (first maximal index), one wave per sample.
+hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int64_t* counts, hipStream_t stream);
+// Fill a tensor from the counter-based normal stream: dst = mean + std * z (fp16 or fp32 destination, 2-D with ld).
+hipError_t launch_fill_normal(void* dst, int is_f16, int64_t rows, int64_t cols, int64_t ld, float mean, float std,
+                              uint64_t seed, uint64_t tensor_id, hipStream_t stream);
+hipError_t launch_fill_const(float* dst, int64_t n, float v, hipStream_t stream);
+// fp16 <-> fp32 2-D copies with leading dims (weight upload / download)
+hipError_t launch_f32_to_f16(const float* src, int64_t lds, half_t* dst, int64_t ldd, int64_t rows, int64_t cols,
+                             hipStream_t stream);
+hipError_t launch_f16_to_f32(const half_t* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols,
+                             hipStream_t stream);
+
+}  // namespace cgpt

@@ -1,0 +1,657 @@
+// model.hip -- the handle behind include/cgpt.h: weights in HBM, the workspace, and the launch sequence of one
+// base-classifier forward (what `self.base_classifier(batch + noise)` does at smoothing.py:97 when the classifier
+// is MiniGPT-4's image encoder, minigpt4.py:121-149).
+//
+// HBM layout (one handle = one GPU; everything stays resident, nothing is re-allocated per call):
+//   weights    fp16 matrices [round_up(N,128)][round_up(K,64)] zero padded (nn.Linear layout, K contiguous);
+//              fp32 vectors for biases / LayerNorm affine / cls_token / pos_embed / query_tokens.
+//   workspace  sized for max_batch samples: im2col A [nb*P][640] fp16, residual stream [nb*T][D] fp32,
+//              LayerNorm output / attention output [nb*T][D] fp16, qkv [nb*T][3D] fp16, MLP hidden [nb*T][6144] fp16, ...
+//              Row counts are padded to 128 and K-dims to 64 so every GEMM tile load is in bounds; pad columns
+//              are zero at allocation and never written.
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cgpt.h"
+#include "common_host.h"
+#include "kernels.h"
+
+using namespace cgpt;
+
+// ------------------------------------------------------------------------------------------- errors
+static thread_local std::string g_last_error;
+cgpt_status cgpt_fail(cgpt_status code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return cgpt_fail(CGPT_ERR_HIP, std::string(#expr) + " -> " + hipGetErrorString(e_));       \
+    } while (0)
+#define CGCHK(expr)                         \
+    do {                                    \
+        cgpt_status s_ = (expr);            \
+        if (s_ != CGPT_OK) return s_;       \
+    } while (0)
+
+static inline int64_t ru(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------- model
+namespace {
+
+enum InitKind { INIT_ZERO = 0, INIT_ONE = 1, INIT_NORMAL = 2 };
+
+struct View {          // a named parameter: a [rows, cols] window of a device buffer
+    std::string name;
+    void* base = nullptr;
+    bool f16 = false;
+    int64_t rows = 0, cols = 0, ld = 0, off = 0;
+    int init = INIT_ZERO;
+    float init_std = 0.f;
+};
+
+struct VitLayer {
+    float *n1w, *n1b, *n2w, *n2b, *bqkv, *bproj, *bfc1, *bfc2;
+    half_t *Wqkv, *Wproj, *Wfc1, *Wfc2;
+};
+struct QfLayer {
+    half_t *Wqkv, *Wo, *Wxq, *Wxo, *Wi, *Wo2;
+    float *bqkv, *bo, *lnw, *lnb, *bxq, *bxo, *xlnw, *xlnb, *bi, *bo2, *ln2w, *ln2b;
+    int xattn_index;   // -1 when the layer has no cross-attention
+};
+struct ProfEvent { hipEvent_t a, b; double flops; int kind; };
+
+}  // namespace
+
+struct cgpt_model {
+    cgpt_config cfg;
+    int P, T, D, Dk, Kpatch, Kpatch_p, mlp, mlp_k, K;           // ViT derived dims
+    int H, Hk, F, Fk, Q, nx, PD, PDk;                            // Q-Former derived dims
+    int64_t ld_qkv, ld_kv;
+    std::vector<void*> allocs;
+    std::vector<View> views;
+    std::map<std::string, int> index;
+    // weights
+    float *cls, *pos, *bpatch, *lnvw, *lnvb, *qtok, *qembw, *qembb, *bkv_all, *bproj_l, *bhead;
+    half_t *Wpatch, *Wkv_all, *Wproj_l, *Whead;
+    std::vector<VitLayer> vit;
+    std::vector<QfLayer> qf;
+    // workspace
+    half_t *Apatch, *xn, *qkv, *attn, *hid, *cls16, *emb, *kv_all, *qh16, *qqkv, *qctx, *qq, *qff, *pooled;
+    float *resid, *logits, *qemb0, *qh32, *qtmp, *llama;
+    int last_nb = 0;
+    bool profile = false;
+    std::vector<ProfEvent> events;
+};
+
+namespace {
+
+cgpt_status dev_alloc(cgpt_model* m, size_t bytes, void** out) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes ? bytes : 16));
+    HIPCHK(hipMemset(p, 0, bytes ? bytes : 16));
+    m->allocs.push_back(p);
+    *out = p;
+    return CGPT_OK;
+}
+
+void add_view(cgpt_model* m, const std::string& name, void* base, bool f16, int64_t rows, int64_t cols, int64_t ld,
+              int64_t off, int init, float std_) {
+    View v;
+    v.name = name; v.base = base; v.f16 = f16; v.rows = rows; v.cols = cols; v.ld = ld; v.off = off;
+    v.init = init; v.init_std = std_;
+    m->index[name] = (int)m->views.size();
+    m->views.push_back(v);
+}
+
+// fp16 GEMM weight [N,K] (zero padded to [ru(N,128)][ru(K,64)])
+cgpt_status new_mat(cgpt_model* m, int64_t N, int64_t Kd, half_t** out) {
+    void* p;
+    CGCHK(dev_alloc(m, (size_t)ru(N, 128) * ru(Kd, 64) * sizeof(half_t), &p));
+    *out = (half_t*)p;
+    return CGPT_OK;
+}
+cgpt_status new_vec(cgpt_model* m, int64_t n, float** out) {
+    void* p;
+    CGCHK(dev_alloc(m, (size_t)ru(n, 128) * sizeof(float), &p));
+    *out = (float*)p;
+    return CGPT_OK;
+}
+cgpt_status add_mat(cgpt_model* m, const std::string& name, int64_t N, int64_t Kd, float std_, half_t** out) {
+    CGCHK(new_mat(m, N, Kd, out));
+    add_view(m, name, *out, true, N, Kd, ru(Kd, 64), 0, INIT_NORMAL, std_);
+    return CGPT_OK;
+}
+cgpt_status add_vec(cgpt_model* m, const std::string& name, int64_t n, int init, float std_, float** out) {
+    CGCHK(new_vec(m, n, out));
+    add_view(m, name, *out, false, 1, n, n, 0, init, std_);
+    return CGPT_OK;
+}
+// activation buffers
+cgpt_status new_act16(cgpt_model* m, int64_t rows, int64_t cols, half_t** out) {
+    void* p;
+    CGCHK(dev_alloc(m, (size_t)ru(rows, 128) * ru(cols, 64) * sizeof(half_t), &p));
+    *out = (half_t*)p;
+    return CGPT_OK;
+}
+cgpt_status new_act32(cgpt_model* m, int64_t rows, int64_t cols, float** out) {
+    void* p;
+    CGCHK(dev_alloc(m, (size_t)ru(rows, 128) * cols * sizeof(float), &p));
+    *out = (float*)p;
+    return CGPT_OK;
+}
+
+cgpt_status build(cgpt_model* m) {
+    const cgpt_config& c = m->cfg;
+    m->P = (c.img_size / c.patch_size) * (c.img_size / c.patch_size);
+    m->T = m->P + 1;
+    m->D = c.vit_dim; m->Dk = (int)ru(m->D, 64);
+    m->Kpatch = 3 * c.patch_size * c.patch_size; m->Kpatch_p = (int)ru(m->Kpatch, 64);
+    m->mlp = c.vit_mlp; m->mlp_k = (int)ru(m->mlp, 64);
+    m->K = c.num_classes;
+    const bool full = c.mode == CGPT_MODE_ENCODE_IMG;
+    m->H = c.qf_dim; m->Hk = (int)ru(m->H, 64); m->F = c.qf_ffn; m->Fk = (int)ru(m->F, 64); m->Q = c.qf_queries;
+    m->PD = c.proj_dim; m->PDk = (int)ru(m->PD, 64);
+    m->nx = 0;
+    if (full) for (int i = 0; i < c.qf_layers; ++i) if (i % c.qf_xattn_freq == 0) m->nx++;
+    const int D = m->D, T = m->T, H = m->H;
+
+    // ---- weights, registered in the order of oracle/model_oracle.py:param_shapes (tensor id = index)
+    const float S = 0.02f;
+    CGCHK(add_vec(m, "visual_encoder.cls_token", D, INIT_NORMAL, S, &m->cls));
+    {
+        void* p; CGCHK(dev_alloc(m, (size_t)T * D * sizeof(float), &p)); m->pos = (float*)p;
+        add_view(m, "visual_encoder.pos_embed", p, false, T, D, D, 0, INIT_NORMAL, S);
+    }
+    CGCHK(add_mat(m, "visual_encoder.patch_embed.proj.weight", D, m->Kpatch, S, &m->Wpatch));
+    CGCHK(add_vec(m, "visual_encoder.patch_embed.proj.bias", D, INIT_ZERO, 0, &m->bpatch));
+    m->vit.resize(c.vit_depth);
+    for (int i = 0; i < c.vit_depth; ++i) {
+        VitLayer& L = m->vit[i];
+        const std::string b = "visual_encoder.blocks." + std::to_string(i) + ".";
+        const float div = 1.0f / sqrtf(2.0f * (float)(i + 1));            // eva_vit.py:308-314
+        CGCHK(add_vec(m, b + "norm1.weight", D, INIT_ONE, 0, &L.n1w));
+        CGCHK(add_vec(m, b + "norm1.bias", D, INIT_ZERO, 0, &L.n1b));
+        CGCHK(new_vec(m, 3 * D, &L.bqkv));                                // cat(q_bias, 0, v_bias), eva_vit.py:127
+        add_view(m, b + "attn.q_bias", L.bqkv, false, 1, D, D, 0, INIT_ZERO, 0);
+        add_view(m, b + "attn.v_bias", L.bqkv, false, 1, D, D, 2 * D, INIT_ZERO, 0);
+        CGCHK(add_mat(m, b + "attn.qkv.weight", 3 * D, D, S, &L.Wqkv));
+        CGCHK(add_mat(m, b + "attn.proj.weight", D, D, S * div, &L.Wproj));
+        CGCHK(add_vec(m, b + "attn.proj.bias", D, INIT_ZERO, 0, &L.bproj));
+        CGCHK(add_vec(m, b + "norm2.weight", D, INIT_ONE, 0, &L.n2w));
+        CGCHK(add_vec(m, b + "norm2.bias", D, INIT_ZERO, 0, &L.n2b));
+        CGCHK(add_mat(m, b + "mlp.fc1.weight", m->mlp, D, S, &L.Wfc1));
+        CGCHK(add_vec(m, b + "mlp.fc1.bias", m->mlp, INIT_ZERO, 0, &L.bfc1));
+        CGCHK(add_mat(m, b + "mlp.fc2.weight", D, m->mlp, S * div, &L.Wfc2));
+        CGCHK(add_vec(m, b + "mlp.fc2.bias", D, INIT_ZERO, 0, &L.bfc2));
+    }
+    CGCHK(add_vec(m, "ln_vision.weight", D, INIT_ONE, 0, &m->lnvw));
+    CGCHK(add_vec(m, "ln_vision.bias", D, INIT_ZERO, 0, &m->lnvb));
+    if (full) {
+        {
+            void* p; CGCHK(dev_alloc(m, (size_t)m->Q * H * sizeof(float), &p)); m->qtok = (float*)p;
+            add_view(m, "query_tokens", p, false, m->Q, H, H, 0, INIT_NORMAL, S);
+        }
+        CGCHK(add_vec(m, "Qformer.bert.embeddings.LayerNorm.weight", H, INIT_ONE, 0, &m->qembw));
+        CGCHK(add_vec(m, "Qformer.bert.embeddings.LayerNorm.bias", H, INIT_ZERO, 0, &m->qembb));
+        // K/V projections of all cross-attention layers share their input (image_embeds): one [nx*2H, D] weight
+        CGCHK(new_mat(m, (int64_t)m->nx * 2 * H, D, &m->Wkv_all));
+        CGCHK(new_vec(m, (int64_t)m->nx * 2 * H, &m->bkv_all));
+        m->qf.resize(c.qf_layers);
+        int xi = 0;
+        for (int i = 0; i < c.qf_layers; ++i) {
+            QfLayer& L = m->qf[i];
+            const std::string lp = "Qformer.bert.encoder.layer." + std::to_string(i) + ".";
+            // self-attention: query/key/value fused into one [3H, H] GEMM
+            CGCHK(new_mat(m, 3 * H, H, &L.Wqkv));
+            CGCHK(new_vec(m, 3 * H, &L.bqkv));
+            const char* qkvn[3] = {"query", "key", "value"};
+            for (int j = 0; j < 3; ++j) {
+                add_view(m, lp + "attention.self." + qkvn[j] + ".weight", L.Wqkv, true, H, H, m->Hk, (int64_t)j * H * m->Hk,
+                         INIT_NORMAL, S);
+                add_view(m, lp + "attention.self." + qkvn[j] + ".bias", L.bqkv, false, 1, H, H, (int64_t)j * H, INIT_ZERO, 0);
+            }
+            CGCHK(add_mat(m, lp + "attention.output.dense.weight", H, H, S, &L.Wo));
+            CGCHK(add_vec(m, lp + "attention.output.dense.bias", H, INIT_ZERO, 0, &L.bo));
+            CGCHK(add_vec(m, lp + "attention.output.LayerNorm.weight", H, INIT_ONE, 0, &L.lnw));
+            CGCHK(add_vec(m, lp + "attention.output.LayerNorm.bias", H, INIT_ZERO, 0, &L.lnb));
+            L.xattn_index = -1;
+            if (i % c.qf_xattn_freq == 0) {
+                L.xattn_index = xi;
+                CGCHK(add_mat(m, lp + "crossattention.self.query.weight", H, H, S, &L.Wxq));
+                CGCHK(add_vec(m, lp + "crossattention.self.query.bias", H, INIT_ZERO, 0, &L.bxq));
+                add_view(m, lp + "crossattention.self.key.weight", m->Wkv_all, true, H, D, m->Dk,
+                         (int64_t)(xi * 2) * H * m->Dk, INIT_NORMAL, S);
+                add_view(m, lp + "crossattention.self.key.bias", m->bkv_all, false, 1, H, H, (int64_t)(xi * 2) * H, INIT_ZERO, 0);
+                add_view(m, lp + "crossattention.self.value.weight", m->Wkv_all, true, H, D, m->Dk,
+                         (int64_t)(xi * 2 + 1) * H * m->Dk, INIT_NORMAL, S);
+                add_view(m, lp + "crossattention.self.value.bias", m->bkv_all, false, 1, H, H, (int64_t)(xi * 2 + 1) * H,
+                         INIT_ZERO, 0);
+                CGCHK(add_mat(m, lp + "crossattention.output.dense.weight", H, H, S, &L.Wxo));
+                CGCHK(add_vec(m, lp + "crossattention.output.dense.bias", H, INIT_ZERO, 0, &L.bxo));
+                CGCHK(add_vec(m, lp + "crossattention.output.LayerNorm.weight", H, INIT_ONE, 0, &L.xlnw));
+                CGCHK(add_vec(m, lp + "crossattention.output.LayerNorm.bias", H, INIT_ZERO, 0, &L.xlnb));
+                ++xi;
+            }
+            CGCHK(add_mat(m, lp + "intermediate_query.dense.weight", m->F, H, S, &L.Wi));
+            CGCHK(add_vec(m, lp + "intermediate_query.dense.bias", m->F, INIT_ZERO, 0, &L.bi));
+            CGCHK(add_mat(m, lp + "output_query.dense.weight", H, m->F, S, &L.Wo2));
+            CGCHK(add_vec(m, lp + "output_query.dense.bias", H, INIT_ZERO, 0, &L.bo2));
+            CGCHK(add_vec(m, lp + "output_query.LayerNorm.weight", H, INIT_ONE, 0, &L.ln2w));
+            CGCHK(add_vec(m, lp + "output_query.LayerNorm.bias", H, INIT_ZERO, 0, &L.ln2b));
+        }
+        CGCHK(add_mat(m, "llama_proj.weight", m->PD, H, S, &m->Wproj_l));
+        CGCHK(add_vec(m, "llama_proj.bias", m->PD, INIT_ZERO, 0, &m->bproj_l));
+        CGCHK(add_mat(m, "head.weight", m->K, m->PD, 0.05f, &m->Whead));
+    } else {
+        CGCHK(add_mat(m, "head.weight", m->K, D, 0.05f, &m->Whead));
+    }
+    CGCHK(add_vec(m, "head.bias", m->K, INIT_ZERO, 0, &m->bhead));
+
+    // ---- workspace for max_batch samples
+    const int64_t nb = c.max_batch, M = nb * T;
+    m->ld_qkv = 3 * D;
+    CGCHK(new_act16(m, nb * m->P, m->Kpatch_p, &m->Apatch));
+    CGCHK(new_act32(m, M, D, &m->resid));
+    CGCHK(new_act16(m, M, D, &m->xn));
+    CGCHK(new_act16(m, M, 3 * D, &m->qkv));
+    CGCHK(new_act16(m, M, D, &m->attn));
+    CGCHK(new_act16(m, M, m->mlp, &m->hid));
+    CGCHK(new_act16(m, nb, D, &m->cls16));
+    CGCHK(new_act32(m, nb, m->K, &m->logits));
+    if (full) {
+        const int64_t MQ = nb * m->Q;
+        m->ld_kv = (int64_t)m->nx * 2 * H;
+        CGCHK(new_act16(m, M, D, &m->emb));
+        CGCHK(new_act16(m, M, m->ld_kv, &m->kv_all));
+        CGCHK(new_act32(m, m->Q, H, &m->qemb0));
+        CGCHK(new_act32(m, MQ, H, &m->qh32));
+        CGCHK(new_act16(m, MQ, H, &m->qh16));
+        CGCHK(new_act16(m, MQ, 3 * H, &m->qqkv));
+        CGCHK(new_act16(m, MQ, H, &m->qctx));
+        CGCHK(new_act16(m, MQ, H, &m->qq));
+        CGCHK(new_act16(m, MQ, m->F, &m->qff));
+        CGCHK(new_act32(m, MQ, H, &m->qtmp));
+        CGCHK(new_act32(m, MQ, m->PD, &m->llama));
+        CGCHK(new_act16(m, nb, m->PD, &m->pooled));
+    }
+    return CGPT_OK;
+}
+
+// ---- launch helpers -------------------------------------------------------------------------------
+cgpt_status gemm(cgpt_model* m, int epi, const half_t* A, int64_t lda, const half_t* W, int64_t ldw, const float* bias,
+                 void* out, int64_t ldo, const float* aux, int64_t ldaux, int M, int N, int Kd, int kind, hipStream_t st) {
+    GemmParams p;
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.out = out; p.ldo = ldo; p.aux = aux; p.ldaux = ldaux;
+    p.M = M; p.N = N; p.K = Kd; p.patches = m->P;
+    ProfEvent ev;
+    if (m->profile) {
+        HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
+        HIPCHK(hipEventRecord(ev.a, st));
+    }
+    HIPCHK(launch_gemm(epi, p, st));
+    if (m->profile) {
+        HIPCHK(hipEventRecord(ev.b, st));
+        ev.flops = 2.0 * (double)M * (double)N * (double)Kd; ev.kind = kind;
+        m->events.push_back(ev);
+    }
+    return CGPT_OK;
+}
+
+cgpt_status attention(const half_t* Q, int64_t ldq, int64_t qbs, const half_t* K, int64_t ldk, const half_t* V, int64_t ldv,
+                      int64_t kvbs, half_t* O, int64_t ldo, int64_t obs, int B, int heads, int hd, int Tq, int Tk,
+                      hipStream_t st) {
+    AttnParams p;
+    p.Q = Q; p.ldq = ldq; p.q_batch_stride = qbs; p.K = K; p.ldk = ldk; p.V = V; p.ldv = ldv; p.kv_batch_stride = kvbs;
+    p.O = O; p.ldo = ldo; p.o_batch_stride = obs; p.B = B; p.heads = heads; p.head_dim = hd; p.Tq = Tq; p.Tk = Tk;
+    p.scale = 1.0f / sqrtf((float)hd);             // eva_vit.py:79 head_dim**-0.5; Qformer.py:244 / sqrt(head_size)
+    HIPCHK(launch_attention(p, st));
+    return CGPT_OK;
+}
+
+// One base-classifier forward for nb samples.  src: the clean image (noise=true) or nb images (noise=false).
+cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_sample, int nb, float sigma, uint64_t seed,
+                    hipStream_t st) {
+    const cgpt_config& c = m->cfg;
+    const int D = m->D, Dk = m->Dk, T = m->T, P = m->P, M = nb * T;
+    // K1 + im2col: smoothing.py:95-96 fused into the patch-embed operand (eva_vit.py:202,209)
+    if (noise) HIPCHK(launch_noise_im2col(src, c.img_size, c.patch_size, first_sample, nb, sigma, seed, m->Apatch, m->Kpatch_p, st));
+    else HIPCHK(launch_im2col(src, c.img_size, c.patch_size, nb, m->Apatch, m->Kpatch_p, st));
+    // patch-embed GEMM + bias + pos_embed, scattered to token rows 1..P; CLS row = cls + pos[0]  (eva_vit.py:333-340)
+    CGCHK(gemm(m, EPI_PATCH, m->Apatch, m->Kpatch_p, m->Wpatch, m->Kpatch_p, m->bpatch, m->resid, D, m->pos, D, nb * P, D,
+               m->Kpatch_p, 0, st));
+    HIPCHK(launch_cls_rows(m->cls, m->pos, m->resid, D, T, nb, D, st));
+    const int hd = D / c.vit_heads;
+    for (int i = 0; i < c.vit_depth; ++i) {                                   // Block.forward, eva_vit.py:178-185
+        const VitLayer& L = m->vit[i];
+        HIPCHK(launch_layernorm(m->resid, D, L.n1w, L.n1b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st));
+        CGCHK(gemm(m, EPI_F16, m->xn, Dk, L.Wqkv, Dk, L.bqkv, m->qkv, m->ld_qkv, nullptr, 0, M, 3 * D, Dk, 0, st));
+        CGCHK(attention(m->qkv, m->ld_qkv, (int64_t)T * m->ld_qkv, m->qkv + D, m->ld_qkv, m->qkv + 2 * D, m->ld_qkv,
+                        (int64_t)T * m->ld_qkv, m->attn, Dk, (int64_t)T * Dk, nb, c.vit_heads, hd, T, T, st));
+        CGCHK(gemm(m, EPI_RESID, m->attn, Dk, L.Wproj, Dk, L.bproj, m->resid, D, m->resid, D, M, D, Dk, 0, st));
+        HIPCHK(launch_layernorm(m->resid, D, L.n2w, L.n2b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st));
+        CGCHK(gemm(m, EPI_F16_GELU, m->xn, Dk, L.Wfc1, Dk, L.bfc1, m->hid, m->mlp_k, nullptr, 0, M, m->mlp, Dk, 1, st));
+        CGCHK(gemm(m, EPI_RESID, m->hid, m->mlp_k, L.Wfc2, m->mlp_k, L.bfc2, m->resid, D, m->resid, D, M, D, m->mlp_k, 0, st));
+    }
+    if (c.mode == CGPT_MODE_VIT_HEAD) {
+        // ln_vision on the CLS rows only (row stride T*D), then the build-side head
+        HIPCHK(launch_layernorm(m->resid, (int64_t)T * D, m->lnvw, m->lnvb, c.ln_vision_eps, m->cls16, Dk, nullptr, 0, nb, D, st));
+        CGCHK(gemm(m, EPI_F32, m->cls16, Dk, m->Whead, Dk, m->bhead, m->logits, m->K, nullptr, 0, nb, m->K, Dk, 0, st));
+        m->last_nb = nb;
+        return CGPT_OK;
+    }
+    // ---- MiniGPT4.encode_img tail: ln_vision -> Q-Former -> llama_proj (minigpt4.py:129-141)
+    const int H = m->H, Hk = m->Hk, Q = m->Q, MQ = nb * Q, qhd = H / c.qf_heads;
+    HIPCHK(launch_layernorm(m->resid, D, m->lnvw, m->lnvb, c.ln_vision_eps, m->emb, Dk, nullptr, 0, M, D, st));
+    // K/V of every cross-attention layer in one GEMM over the image tokens (Qformer.py:185-188,203-204)
+    CGCHK(gemm(m, EPI_F16, m->emb, Dk, m->Wkv_all, Dk, m->bkv_all, m->kv_all, m->ld_kv, nullptr, 0, M, (int)m->ld_kv, Dk, 0, st));
+    // embeddings: LayerNorm(query_tokens) (Qformer.py:104-106), expanded over the batch (minigpt4.py:132)
+    HIPCHK(launch_layernorm(m->qtok, H, m->qembw, m->qembb, c.qf_ln_eps, nullptr, 0, m->qemb0, H, Q, H, st));
+    HIPCHK(launch_broadcast_rows(m->qemb0, Q, H, nb, m->qh32, H, m->qh16, Hk, st));
+    for (int i = 0; i < c.qf_layers; ++i) {                                   // BertLayer.forward, Qformer.py:402-474
+        const QfLayer& L = m->qf[i];
+        CGCHK(gemm(m, EPI_F16, m->qh16, Hk, L.Wqkv, Hk, L.bqkv, m->qqkv, 3 * H, nullptr, 0, MQ, 3 * H, Hk, 0, st));
+        CGCHK(attention(m->qqkv, 3 * H, (int64_t)Q * 3 * H, m->qqkv + H, 3 * H, m->qqkv + 2 * H, 3 * H, (int64_t)Q * 3 * H,
+                        m->qctx, Hk, (int64_t)Q * Hk, nb, c.qf_heads, qhd, Q, Q, st));
+        CGCHK(gemm(m, EPI_RESID, m->qctx, Hk, L.Wo, Hk, L.bo, m->qtmp, H, m->qh32, H, MQ, H, Hk, 0, st));   // Qformer.py:285-288
+        HIPCHK(launch_layernorm(m->qtmp, H, L.lnw, L.lnb, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
+        if (L.xattn_index >= 0) {                                            // Qformer.py:432-447
+            const half_t* Kx = m->kv_all + (int64_t)L.xattn_index * 2 * H;
+            CGCHK(gemm(m, EPI_F16, m->qh16, Hk, L.Wxq, Hk, L.bxq, m->qq, Hk, nullptr, 0, MQ, H, Hk, 0, st));
+            CGCHK(attention(m->qq, Hk, (int64_t)Q * Hk, Kx, m->ld_kv, Kx + H, m->ld_kv, (int64_t)T * m->ld_kv, m->qctx, Hk,
+                            (int64_t)Q * Hk, nb, c.qf_heads, qhd, Q, T, st));
+            CGCHK(gemm(m, EPI_RESID, m->qctx, Hk, L.Wxo, Hk, L.bxo, m->qtmp, H, m->qh32, H, MQ, H, Hk, 0, st));
+            HIPCHK(launch_layernorm(m->qtmp, H, L.xlnw, L.xlnb, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
+        }
+        // feed_forward_chunk_query, Qformer.py:481-484
+        CGCHK(gemm(m, EPI_F16_GELU, m->qh16, Hk, L.Wi, Hk, L.bi, m->qff, m->Fk, nullptr, 0, MQ, m->F, Hk, 0, st));
+        CGCHK(gemm(m, EPI_RESID, m->qff, m->Fk, L.Wo2, m->Fk, L.bo2, m->qtmp, H, m->qh32, H, MQ, H, m->Fk, 0, st));
+        HIPCHK(launch_layernorm(m->qtmp, H, L.ln2w, L.ln2b, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
+    }
+    CGCHK(gemm(m, EPI_F32, m->qh16, Hk, m->Wproj_l, Hk, m->bproj_l, m->llama, m->PD, nullptr, 0, MQ, m->PD, Hk, 0, st));
+    // build-side label head on the mean of the query tokens
+    HIPCHK(launch_mean_rows(m->llama, m->PD, Q, m->PD, nb, m->pooled, m->PDk, st));
+    CGCHK(gemm(m, EPI_F32, m->pooled, m->PDk, m->Whead, m->PDk, m->bhead, m->logits, m->K, nullptr, 0, nb, m->K, m->PDk, 0, st));
+    m->last_nb = nb;
+    return CGPT_OK;
+}
+
+const View* find_view(cgpt_model* m, const char* name) {
+    if (!m || !name) return nullptr;
+    auto it = m->index.find(name);
+    return it == m->index.end() ? nullptr : &m->views[it->second];
+}
+
+}  // namespace
+
+// =========================================================================================== C-ABI
+extern "C" {
+
+const char* cgpt_last_error(void) { return g_last_error.c_str(); }
+const char* cgpt_version(void) { return "cgpt 0.1 (gfx950)"; }
+
+cgpt_status cgpt_create(const cgpt_config* cfg, cgpt_handle* out) {
+    if (!cfg || !out) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(cgpt_config))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: cgpt_config.struct_size mismatch (header/library drift)");
+    const cgpt_config& c = *cfg;
+    if (c.mode != CGPT_MODE_VIT_HEAD && c.mode != CGPT_MODE_ENCODE_IMG) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: bad mode");
+    if (c.num_classes < 1 || c.max_batch < 1 || c.img_size < 1 || c.patch_size < 1 || c.img_size % c.patch_size ||
+        (c.img_size & 3) || c.vit_dim < 8 || (c.vit_dim & 7) || c.vit_depth < 1 || c.vit_heads < 1 || c.vit_dim % c.vit_heads ||
+        c.vit_mlp < 8 || (c.vit_mlp & 7))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: bad ViT dimensions");
+    const int hd = c.vit_dim / c.vit_heads;
+    if (hd != 88 && hd != 64) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: ViT head_dim must be 88 or 64");
+    const int T = (c.img_size / c.patch_size) * (c.img_size / c.patch_size) + 1;
+    if (T > 288) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: more than 288 tokens (448^2 images) is not supported yet");
+    if (c.mode == CGPT_MODE_ENCODE_IMG) {
+        if (c.qf_layers < 1 || c.qf_dim < 8 || c.qf_heads < 1 || c.qf_dim % c.qf_heads || c.qf_dim / c.qf_heads != 64 ||
+            c.qf_ffn < 8 || (c.qf_ffn & 7) || c.qf_queries < 1 || c.qf_queries > 32 || c.qf_xattn_freq < 1 || c.proj_dim < 8 ||
+            (c.proj_dim & 7))
+            return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: bad Q-Former dimensions (head_dim 64, <= 32 queries)");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return cgpt_fail(CGPT_ERR_NO_DEVICE, "cgpt_create: no HIP device visible (this library has no CPU fallback)");
+    if (c.device < 0 || c.device >= ndev) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: bad device ordinal");
+    HIPCHK(hipSetDevice(c.device));
+    cgpt_model* m = new cgpt_model();
+    m->cfg = c;
+    cgpt_status s = build(m);
+    if (s != CGPT_OK) { cgpt_destroy(m); return s; }
+    HIPCHK(hipDeviceSynchronize());
+    *out = m;
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_destroy(cgpt_handle h) {
+    if (!h) return CGPT_OK;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+    return CGPT_OK;
+}
+
+int64_t cgpt_weight_numel(cgpt_handle h, const char* name) {
+    const View* v = find_view(h, name);
+    return v ? v->rows * v->cols : -1;
+}
+const char* cgpt_weight_name(cgpt_handle h, int32_t index) {
+    if (!h || index < 0 || index >= (int32_t)h->views.size()) return nullptr;
+    return h->views[index].name.c_str();
+}
+
+cgpt_status cgpt_load_weight(cgpt_handle h, const char* name, const float* data_host, int64_t numel) {
+    if (!h || !name || !data_host) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_load_weight: null argument");
+    const View* v = find_view(h, name);
+    if (!v) return cgpt_fail(CGPT_ERR_NOT_FOUND, std::string("cgpt_load_weight: unknown weight '") + name + "'");
+    if (numel != v->rows * v->cols)
+        return cgpt_fail(CGPT_ERR_INVALID, std::string("cgpt_load_weight: '") + name + "' expects " +
+                                               std::to_string(v->rows * v->cols) + " elements, got " + std::to_string(numel));
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (v->f16) {
+        float* tmp = nullptr;
+        HIPCHK(hipMalloc(&tmp, (size_t)numel * sizeof(float)));
+        hipError_t e = hipMemcpy(tmp, data_host, (size_t)numel * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_f32_to_f16(tmp, v->cols, (half_t*)v->base + v->off, v->ld, v->rows, v->cols, 0);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        (void)hipFree(tmp);
+        HIPCHK(e);
+    } else {
+        HIPCHK(hipMemcpy2D((float*)v->base + v->off, (size_t)v->ld * sizeof(float), data_host, (size_t)v->cols * sizeof(float),
+                           (size_t)v->cols * sizeof(float), (size_t)v->rows, hipMemcpyHostToDevice));
+    }
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_get_weight(cgpt_handle h, const char* name, float* out_host, int64_t numel) {
+    if (!h || !name || !out_host) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_get_weight: null argument");
+    const View* v = find_view(h, name);
+    if (!v) return cgpt_fail(CGPT_ERR_NOT_FOUND, std::string("cgpt_get_weight: unknown weight '") + name + "'");
+    if (numel != v->rows * v->cols) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_get_weight: numel mismatch");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    if (v->f16) {
+        float* tmp = nullptr;
+        HIPCHK(hipMalloc(&tmp, (size_t)numel * sizeof(float)));
+        hipError_t e = launch_f16_to_f32((const half_t*)v->base + v->off, v->ld, tmp, v->cols, v->rows, v->cols, 0);
+        if (e == hipSuccess) e = hipMemcpy(out_host, tmp, (size_t)numel * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        HIPCHK(e);
+    } else {
+        HIPCHK(hipMemcpy2D(out_host, (size_t)v->cols * sizeof(float), (const float*)v->base + v->off,
+                           (size_t)v->ld * sizeof(float), (size_t)v->cols * sizeof(float), (size_t)v->rows, hipMemcpyDeviceToHost));
+    }
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_init_synthetic_weights(cgpt_handle h, uint64_t seed, void* stream) {
+    if (!h) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_init_synthetic_weights: null handle");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    for (size_t i = 0; i < h->views.size(); ++i) {
+        const View& v = h->views[i];
+        if (v.init == INIT_NORMAL) {
+            void* dst = v.f16 ? (void*)((half_t*)v.base + v.off) : (void*)((float*)v.base + v.off);
+            HIPCHK(launch_fill_normal(dst, v.f16 ? 1 : 0, v.rows, v.cols, v.ld, 0.0f, v.init_std, seed, (uint64_t)i, st));
+        } else {
+            // 1-D fp32 parameters (rows == 1): LayerNorm weight 1, every bias 0 (eva_vit.py:316-323)
+            HIPCHK(launch_fill_const((float*)v.base + v.off, v.cols, v.init == INIT_ONE ? 1.0f : 0.0f, st));
+        }
+    }
+    return CGPT_OK;
+}
+
+static cgpt_status check_call(cgpt_handle h, const void* p1, const void* p2, int64_t num, const char* who) {
+    if (!h || !p1 || !p2) return cgpt_fail(CGPT_ERR_INVALID, std::string(who) + ": null argument");
+    if (num < 0) return cgpt_fail(CGPT_ERR_INVALID, std::string(who) + ": negative sample count");
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_sample_counts(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num, int64_t batch_size,
+                               float sigma, uint64_t noise_seed, int64_t* counts_dev, void* stream) {
+    CGCHK(check_call(h, x_dev, counts_dev, num, "cgpt_sample_counts"));
+    if (batch_size < 1 || batch_size > h->cfg.max_batch)
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_sample_counts: batch_size must be in [1, max_batch]");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int64_t done = 0;
+    while (done < num) {                                   // smoothing.py:91-98
+        const int nb = (int)((num - done < batch_size) ? (num - done) : batch_size);
+        CGCHK(forward(h, x_dev, true, first_sample + done, nb, sigma, noise_seed, st));
+        HIPCHK(launch_vote(h->logits, h->K, nb, h->K, counts_dev, st));
+        done += nb;
+    }
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_forward_logits(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num, float sigma,
+                                uint64_t noise_seed, float* logits_dev, void* stream) {
+    CGCHK(check_call(h, x_dev, logits_dev, num, "cgpt_forward_logits"));
+    if (num < 1 || num > h->cfg.max_batch) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_forward_logits: num must be in [1, max_batch]");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CGCHK(forward(h, x_dev, true, first_sample, (int)num, sigma, noise_seed, st));
+    HIPCHK(hipMemcpyAsync(logits_dev, h->logits, (size_t)num * h->K * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_classify(cgpt_handle h, const float* images_dev, int64_t num, float* logits_dev, void* stream) {
+    CGCHK(check_call(h, images_dev, logits_dev, num, "cgpt_classify"));
+    if (num < 1 || num > h->cfg.max_batch) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_classify: num must be in [1, max_batch]");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CGCHK(forward(h, images_dev, false, 0, (int)num, 0.f, 0, st));
+    HIPCHK(hipMemcpyAsync(logits_dev, h->logits, (size_t)num * h->K * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_get_activation(cgpt_handle h, const char* what, float* out_dev, int64_t numel, void* stream) {
+    if (!h || !what || !out_dev) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_get_activation: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = h->last_nb;
+    if (nb <= 0) return cgpt_fail(CGPT_ERR_STATE, "cgpt_get_activation: no forward has run");
+    const std::string w(what);
+    const bool full = h->cfg.mode == CGPT_MODE_ENCODE_IMG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (w == "vit_out") {
+        if (numel != (int64_t)nb * h->T * h->D) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_get_activation: numel mismatch");
+        HIPCHK(hipMemcpyAsync(out_dev, h->resid, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (w == "ln_vision" && full) {
+        if (numel != (int64_t)nb * h->T * h->D) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_get_activation: numel mismatch");
+        HIPCHK(launch_f16_to_f32(h->emb, h->Dk, out_dev, h->D, (int64_t)nb * h->T, h->D, st));
+    } else if (w == "qformer" && full) {
+        if (numel != (int64_t)nb * h->Q * h->H) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_get_activation: numel mismatch");
+        HIPCHK(hipMemcpyAsync(out_dev, h->qh32, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (w == "llama" && full) {
+        if (numel != (int64_t)nb * h->Q * h->PD) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_get_activation: numel mismatch");
+        HIPCHK(hipMemcpyAsync(out_dev, h->llama, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        return cgpt_fail(CGPT_ERR_NOT_FOUND, "cgpt_get_activation: unknown activation for this mode");
+    }
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_noise_batch(const float* x_dev, int64_t chw, int64_t first_sample, int64_t num, float sigma,
+                             uint64_t noise_seed, float* out_dev, void* stream) {
+    if (!x_dev || !out_dev || chw < 1 || num < 0) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_noise_batch: bad argument");
+    HIPCHK(launch_noise_batch(x_dev, chw, first_sample, num, sigma, noise_seed, out_dev, (hipStream_t)stream));
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes, int64_t* counts_dev, void* stream) {
+    if (!logits_dev || !counts_dev || num < 0 || num_classes < 1) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_vote: bad argument");
+    HIPCHK(launch_vote(logits_dev, num_classes, num, num_classes, counts_dev, (hipStream_t)stream));
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on) {
+    if (!h) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_profile_enable: null handle");
+    h->profile = on != 0;
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, double* total_flops, int64_t* launches) {
+    if (!h || !total_ms || !total_flops || !launches) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_profile_read: null argument");
+    double ms = 0, fl = 0; int64_t n = 0;
+    for (auto& e : h->events) {
+        HIPCHK(hipEventSynchronize(e.b));
+        if (kind == 0 || e.kind == kind) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, e.a, e.b));
+            ms += t; fl += e.flops; ++n;
+        }
+    }
+    if (kind == 0) {   // reading "all" drains the log
+        for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        h->events.clear();
+    }
+    *total_ms = ms; *total_flops = fl; *launches = n;
+    return CGPT_OK;
+}
+
+// ---- raw kernels -----------------------------------------------------------------------------------
+cgpt_status cgpt_gemm_f16(const void* A_dev, int64_t lda, const void* W_dev, int64_t ldw, const float* bias_dev,
+                          float* C_dev, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream) {
+    if (!A_dev || !W_dev || !C_dev || M < 1 || N < 1 || K < 64 || (K % 64) || (lda % 8) || (ldw % 8))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_gemm_f16: bad argument (K % 64 == 0, lda/ldw % 8 == 0)");
+    GemmParams p;
+    p.A = (const half_t*)A_dev; p.lda = lda; p.W = (const half_t*)W_dev; p.ldw = ldw; p.bias = bias_dev;
+    p.out = C_dev; p.ldo = ldc; p.aux = nullptr; p.ldaux = 0; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.patches = 1;
+    HIPCHK(launch_gemm(EPI_F32, p, (hipStream_t)stream));
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_attention_f16(const void* Q_dev, int64_t ldq, const void* K_dev, const void* V_dev, int64_t ldkv,
+                               void* O_dev, int64_t ldo, int32_t B, int32_t heads, int32_t head_dim, int32_t Tq, int32_t Tk,
+                               float scale, void* stream) {
+    if (!Q_dev || !K_dev || !V_dev || !O_dev) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_attention_f16: null argument");
+    AttnParams p;
+    p.Q = (const half_t*)Q_dev; p.ldq = ldq; p.q_batch_stride = (int64_t)Tq * ldq;
+    p.K = (const half_t*)K_dev; p.ldk = ldkv; p.V = (const half_t*)V_dev; p.ldv = ldkv; p.kv_batch_stride = (int64_t)Tk * ldkv;
+    p.O = (half_t*)O_dev; p.ldo = ldo; p.o_batch_stride = (int64_t)Tq * ldo;
+    p.B = B; p.heads = heads; p.head_dim = head_dim; p.Tq = Tq; p.Tk = Tk; p.scale = scale;
+    hipError_t e = launch_attention(p, (hipStream_t)stream);
+    if (e != hipSuccess) return cgpt_fail(e == hipErrorInvalidValue ? CGPT_ERR_INVALID : CGPT_ERR_HIP,
+                                          std::string("cgpt_attention_f16: ") + hipGetErrorString(e));
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_layernorm(const float* x_dev, int64_t ldx, const float* gamma_dev, const float* beta_dev, float eps,
+                           void* y_dev, int64_t ldy, float* y32_dev, int64_t ldy32, int64_t rows, int32_t D, void* stream) {
+    if (!x_dev || !gamma_dev || !beta_dev || (!y_dev && !y32_dev)) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_layernorm: null argument");
+    hipError_t e = launch_layernorm(x_dev, ldx, gamma_dev, beta_dev, eps, (half_t*)y_dev, ldy, y32_dev, ldy32, rows, D,
+                                    (hipStream_t)stream);
+    if (e != hipSuccess) return cgpt_fail(e == hipErrorInvalidValue ? CGPT_ERR_INVALID : CGPT_ERR_HIP,
+                                          std::string("cgpt_layernorm: ") + hipGetErrorString(e));
+    return CGPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""Smooth -- drop-in for the reference's randomized_smoothing/smoothing.py:13-117 on MI355X.
+
+Same constructor and method signatures (`Smooth(base_classifier, num_classes, sigma)`, `certify(x, n0, n, alpha,
+batch_size) -> (int, float)`, `predict(x, n, alpha, batch_size) -> int`, `ABSTAIN = -1`), same return
+conventions.  Differences, all build-side and documented in DESIGN.md:
+  * the Monte-Carlo loop (`_sample_noise`, smoothing.py:81-99) runs in libcgpt.so: counter-based Gaussian noise,
+    the HIP classifier, argmax and the vote histogram stay on the GPU; one device->host copy per `_sample_noise`
+    instead of one per batch (smoothing.py:98);
+  * with torch.distributed initialised, the sample range of every `_sample_noise` is sharded over the ranks and the
+    int64 histograms are summed with ONE all-reduce (RCCL over xGMI; gloo in CPU tests);
+  * the statistics (smoothing.py:46-56,73-79,107-117) are float64 host functions of the C-ABI -- no scipy /
+    statsmodels needed at run time.
+There is no CPU fallback: without libcgpt.so import fails, without a GPU the engine cannot be created.
+"""
+import ctypes as C
+from math import ceil
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _world(group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_range(num: int, rank: int, world: int):
+    """Samples [lo, hi) of `num` handled by `rank`: contiguous, remainder to the low ranks."""
+    base, rem = divmod(num, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class Smooth(object):
+    """A smoothed classifier g (smoothing.py:13)."""
+
+    ABSTAIN = -1  # smoothing.py:17
+
+    def __init__(self, base_classifier, num_classes: int, sigma: float, seed: int = 0, process_group=None):
+        """
+        :param base_classifier: an engine exposing `sample_counts(x, first_sample, num, batch_size, sigma, seed)`
+               (certifiedgpt_amd.HipClassifier), or any callable mapping a [B,C,H,W] CUDA tensor to [B,num_classes]
+               logits (e.g. full MiniGPT-4 + label adapter on PyTorch-ROCm): then only noise and vote run in HIP.
+        :param num_classes, sigma: as smoothing.py:19-27
+        :param seed: key of the counter-based noise stream; sample indices never repeat within one Smooth object
+        """
+        self.base_classifier = base_classifier
+        self.num_classes = num_classes
+        self.sigma = sigma
+        self.seed = int(seed)
+        self.process_group = process_group
+        self._next_sample = 0
+        self._lib = _lib.lib()
+
+    # ------------------------------------------------------------------ reference API
+    def certify(self, x: torch.tensor, n0: int, n: int, alpha: float, batch_size: int) -> (int, float):
+        """smoothing.py:29-56.  Returns (predicted class, certified L2 radius) or (ABSTAIN, 0.0)."""
+        self.base_classifier.eval()
+        counts_selection = self._sample_noise(x, n0, batch_size)
+        counts_estimation = self._sample_noise(x, n, batch_size)
+        return self.certify_from_counts(counts_selection, counts_estimation, n, alpha)
+
+    def predict(self, x: torch.tensor, n: int, alpha: float, batch_size: int) -> int:
+        """smoothing.py:58-79.  Returns the predicted class or ABSTAIN."""
+        self.base_classifier.eval()
+        counts = self._sample_noise(x, n, batch_size)
+        return self.predict_from_counts(counts, alpha)
+
+    def _sample_noise(self, x: torch.tensor, num: int, batch_size) -> np.ndarray:
+        """smoothing.py:81-99 -> ndarray[int] of length num_classes with the per-class vote counts."""
+        first = self._next_sample
+        self._next_sample += num
+        rank, world = _world(self.process_group)
+        lo, hi = shard_range(num, rank, world)
+        with torch.no_grad():
+            counts = self._local_counts(x, first + lo, hi - lo, batch_size)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)   # the one collective (C1)
+        return counts.cpu().numpy().astype(int)
+
+    def _count_arr(self, arr: np.ndarray, length: int) -> np.ndarray:
+        """smoothing.py:101-105 (host histogram; the GPU path votes in the HIP kernel instead)."""
+        return np.bincount(np.asarray(arr, dtype=np.int64), minlength=length).astype(int)
+
+    def _lower_confidence_bound(self, NA: int, N: int, alpha: float) -> float:
+        """smoothing.py:107-117: Clopper-Pearson (1 - alpha) lower bound."""
+        return float(self._lib.cgpt_lower_confidence_bound(int(NA), int(N), float(alpha)))
+
+    # ------------------------------------------------------------------ pieces
+    def reset(self, next_sample: int = 0):
+        """Rewind the sample-index cursor (makes a certify call reproducible bit-for-bit)."""
+        self._next_sample = int(next_sample)
+
+    def _local_counts(self, x, first_sample, num, batch_size):
+        bc = self.base_classifier
+        if hasattr(bc, "sample_counts"):
+            return bc.sample_counts(x, first_sample, num, batch_size, float(self.sigma), self.seed)
+        # generic classifier on PyTorch-ROCm: HIP noise -> classifier -> HIP argmax/vote
+        from .classifier import noise_batch, vote
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise RuntimeError("Smooth needs x on a HIP device: certifiedgpt_amd has no CPU path")
+        counts = torch.zeros(self.num_classes, dtype=torch.int64, device=x.device)
+        done = 0
+        for _ in range(ceil(num / batch_size)):
+            this_batch_size = min(batch_size, num - done)
+            batch = noise_batch(x.float(), first_sample + done, this_batch_size, float(self.sigma), self.seed)
+            vote(bc(batch), counts)
+            done += this_batch_size
+        return counts
+
+    def certify_from_counts(self, counts_selection, counts_estimation, n: int, alpha: float):
+        cs = np.ascontiguousarray(counts_selection, dtype=np.int64)
+        ce = np.ascontiguousarray(counts_estimation, dtype=np.int64)
+        label, radius = C.c_int32(), C.c_double()
+        _lib.check(self._lib.cgpt_certify_from_counts(cs.ctypes.data_as(C.c_void_p), ce.ctypes.data_as(C.c_void_p),
+                                                      len(cs), int(n), float(alpha), float(self.sigma),
+                                                      C.byref(label), C.byref(radius)))
+        return int(label.value), float(radius.value)
+
+    def predict_from_counts(self, counts, alpha: float) -> int:
+        c = np.ascontiguousarray(counts, dtype=np.int64)
+        label = C.c_int32()
+        _lib.check(self._lib.cgpt_predict_from_counts(c.ctypes.data_as(C.c_void_p), len(c), float(alpha), C.byref(label)))
+        return int(label.value)

@@ -1,0 +1,125 @@
+"""CPU-only checks of the C-ABI: every symbol of include/cgpt.h is exported, the float64 statistics match the
+goldens emitted by the reference's own smoothing.py, and device entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import certifiedgpt_amd as cg
+from certifiedgpt_amd import _lib
+from oracle import smooth_oracle as so
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "cgpt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cgpt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    L = cg.lib()
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(L, s), f"libcgpt.so does not export {s}"
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+
+
+def test_config_struct_matches_header():
+    text = open(os.path.join(ROOT, "include", "cgpt.h")).read()
+    body = re.search(r"typedef struct cgpt_config \{(.*?)\} cgpt_config;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:int32_t|float)\s+([a-z_0-9]+)\s*;", body)
+    assert fields == [f[0] for f in _lib.Config._fields_]
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(cg.CgptError) as e:
+        cg.HipClassifier(max_batch=2)
+    assert e.value.code == 2  # CGPT_ERR_NO_DEVICE
+
+
+def _smooth(sigma=0.5, K=3):
+    class _Eval:
+        def eval(self):
+            return self
+    return cg.Smooth(_Eval(), K, sigma)
+
+
+def test_certify_from_counts_matches_reference_goldens(stats_golden):
+    worst = 0.0
+    for c in stats_golden["certify"]:
+        s = _smooth(c["sigma"], len(c["counts_sel"]))
+        lab, rad = s.certify_from_counts(c["counts_sel"], c["counts_est"], c["n"], c["alpha"])
+        assert lab == c["label"], c                       # bit-exact decision (vote / abstain logic)
+        assert abs(rad - c["radius"]) <= 1e-3, (c, rad)   # north-star tolerance on R
+        worst = max(worst, abs(rad - c["radius"]))
+    assert worst <= 1e-9                                  # what the implementation actually achieves
+
+
+def test_predict_from_counts_matches_reference_goldens(stats_golden):
+    for c in stats_golden["predict"]:
+        s = _smooth(1.0, len(c["counts"]))
+        out = s.predict_from_counts(c["counts"], c["alpha"])
+        assert out == c["label"] and isinstance(out, int), c
+
+
+def test_scalar_statistics_match_reference_goldens(stats_golden):
+    L = cg.lib()
+    for c in stats_golden["lcb"]:
+        v = L.cgpt_lower_confidence_bound(c["nA"], c["n"], c["alpha"])
+        assert abs(v - c["value"]) <= 1e-11 * max(abs(c["value"]), 1e-3), (c, v)
+    for c in stats_golden["binom_test"]:
+        v = L.cgpt_binom_test(c["k"], c["n"], c["p"])
+        assert abs(v - c["value"]) <= 1e-10 * c["value"] + 1e-300, (c, v)
+    for c in stats_golden["norm_ppf"]:
+        v = L.cgpt_norm_ppf(c["p"])
+        assert abs(v - c["value"]) <= 1e-13 * max(1.0, abs(c["value"])), (c, v)
+    s = _smooth()
+    assert s._lower_confidence_bound(90, 100, 0.001) == pytest.approx(0.7753298801677749, abs=1e-13)
+    for c in stats_golden["count_arr"]:
+        assert s._count_arr(np.asarray(c["arr"], dtype=int), c["length"]).tolist() == c["counts"]
+
+
+def test_product_statistics_agree_with_oracle_on_random_histograms():
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        K = int(rng.choice([2, 3, 10, 1000])); n = int(rng.choice([10, 100, 125, 1000]))
+        p = rng.dirichlet(np.ones(min(K, 5)) * 0.4); pf = np.zeros(K); pf[rng.choice(K, len(p), replace=False)] = p
+        sel, est = rng.multinomial(n, pf), rng.multinomial(n, pf)
+        alpha = float(rng.choice([0.001, 0.01, 0.05])); sigma = float(rng.choice([0.25, 0.5, 1.0]))
+        s = _smooth(sigma, K)
+        lab, rad = s.certify_from_counts(sel, est, n, alpha)
+        olab, orad = so.certify_from_counts(sel, est, n, alpha, sigma)
+        assert lab == olab and abs(rad - orad) <= 1e-9
+        assert s.predict_from_counts(est, alpha) == so.predict_from_counts(est, alpha)
+
+
+def test_bad_arguments_return_status_not_crash():
+    L = cg.lib()
+    lab, rad = C.c_int32(), C.c_double()
+    a = np.zeros(3, dtype=np.int64)
+    p = a.ctypes.data_as(C.c_void_p)
+    assert L.cgpt_certify_from_counts(None, p, 3, 10, 0.001, 0.5, C.byref(lab), C.byref(rad)) == 1
+    assert b"bad argument" in L.cgpt_last_error()
+    assert L.cgpt_predict_from_counts(p, 1, 0.001, C.byref(lab)) == 1      # reference needs >= 2 classes (top2[1])
+    assert L.cgpt_certify_from_counts(p, p, 3, 10, 1.5, 0.5, C.byref(lab), C.byref(rad)) == 1
+    assert L.cgpt_destroy(None) == 0
+
+
+def test_shard_range_partitions_exactly():
+    for num in (0, 1, 7, 10, 100, 125, 1000):
+        for world in (1, 2, 3, 4, 8):
+            parts = [cg.shard_range(num, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == num
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    # N=100 over 8 GPUs -> 13,13,13,13,12,12,12,12
+    assert [hi - lo for lo, hi in (cg.shard_range(100, r, 8) for r in range(8))] == [13] * 4 + [12] * 4

@@ -1,0 +1,81 @@
+"""world_size-2 gloo test of the sharded `_sample_noise` path: each rank votes on its shard of the sample range,
+one all-reduce sums the histograms, every rank then computes identical certify/predict results -- and the result
+equals the single-process one.  The engine here is a CPU stand-in with the `sample_counts` protocol whose votes
+depend only on the GLOBAL sample index (as the HIP engine's counter-based noise does); it exercises the host logic
+of certifiedgpt_amd.Smooth (shard_range, cursor, all-reduce, C-ABI statistics), not the kernels."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import certifiedgpt_amd as cg
+from oracle import philox
+
+K = 7
+
+
+class IndexedEngine:
+    """Votes class (philox word of the global sample index) % K; records the ranges it was asked for."""
+
+    def __init__(self):
+        self.calls = []
+
+    def eval(self):
+        return self
+
+    def sample_counts(self, x, first_sample, num, batch_size, sigma, seed):
+        self.calls.append((first_sample, num, batch_size))
+        idx = np.arange(first_sample, first_sample + num, dtype=np.uint64)
+        r = philox.philox4x32_10(idx, 0, 0, 0, seed, 0)[0]
+        labels = np.where(r % 10 < 7, 3, r % K)           # class 3 wins ~70 %
+        return torch.from_numpy(np.bincount(labels.astype(np.int64), minlength=K).astype(np.int64))
+
+
+def _single():
+    s = cg.Smooth(IndexedEngine(), K, 0.5, seed=11)
+    x = torch.zeros(3, 8, 8)
+    return s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = IndexedEngine()
+        s = cg.Smooth(eng, K, 0.5, seed=11)
+        x = torch.zeros(3, 8, 8)
+        out = (s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist())
+        q.put((rank, out, eng.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_gloo_matches_single_process():
+    expect = _single()
+    assert expect[0][0] == 3 and expect[0][1] > 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, calls in got:
+        assert out == expect, (rank, out, expect)          # identical label / radius / counts on every rank
+    # rank 0 took [0,50) of the selection pass, rank 1 [50,100); estimation pass starts at global index 100
+    assert got[0][2][:2] == [(0, 50, 32), (100, 50, 32)]
+    assert got[1][2][:2] == [(50, 50, 32), (150, 50, 32)]
+    # predict: 125 samples -> 63 + 62, starting at cursor 200
+    assert got[0][2][2] == (200, 63, 32) and got[1][2][2] == (263, 62, 32)
