@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- certified images / s on MI355X (BASELINE.json metric).
+
+One "step" = one `Smooth.certify(x, n0=100, n=100, alpha=0.001, batch_size)` of one synthetic 224x224 image at
+sigma = 0.5 through EVA-ViT-G (random-init weights of that architecture) + ln_vision(CLS) + Linear(1408->1000) head
+(BASELINE.json configs[1]); i.e. n0 + n = 200 classifier forwards (reference smoothing.py:44,48).
+With N GPUs the Monte-Carlo samples of every `_sample_noise` are sharded over the ranks and the int64 vote histograms are
+summed with one RCCL all-reduce (strong scaling: the work per certified image is fixed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the MLP fc1 GEMM with the GELU epilogue,
+gemm_f16_kernel<EPI_F16_GELU>): achieved = 2*M*6144*1408 FLOP per launch / its mean launch duration measured with HIP
+events on the launch stream inside the timed region.  `cpu_baseline` times the CPU oracle (oracle/, a port of the
+reference's Smooth + ViT-G forward in fp32 PyTorch) on the host cores, on a bounded sample, on rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N0, N, ALPHA, SIGMA, NUM_CLASSES = 100, 100, 0.001, 0.5, 1000
+F_VIT = 520_719_260_160          # FLOP per 224^2 sample, ViT-G GEMMs + attention (SURVEY.md 8(d) / BASELINE.md section 2)
+MFMA_PEAK_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md chip table
+
+
+def synthetic_images(count, device):
+    """x = (u - mean)/std, u ~ U[0,1): CLIP-normalised space, where the reference adds its noise
+    (processors/base_processor.py:18-20)."""
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    u = torch.rand(count, 3, 224, 224, generator=g)
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    return ((u - mean) / std).to(device)
+
+
+def cpu_baseline(clf, x, seconds_budget=25.0):
+    """The oracle's Smooth hot loop on the host cores, same weights / image / noise stream as the GPU run, bounded sample."""
+    import numpy as np
+    import certifiedgpt_amd as cg
+    from oracle import model_oracle as mo
+    cfg = mo.Config(mode=mo.MODE_VIT_HEAD, num_classes=NUM_CLASSES)
+    params = {n: torch.from_numpy(clf.get_weight(n)).reshape(s) for n, s in mo.param_shapes(cfg).items()}
+    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("CGPT_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    bs, done, t_used = 4, 0, 0.0
+    counts = np.zeros(NUM_CLASSES, dtype=int)
+    while True:
+        noisy = cg.noise_batch(x, done, bs, SIGMA, 42).cpu()          # identical draws to the GPU stream
+        t0 = time.perf_counter()
+        logits = mo.forward_all(params, noisy, cfg)["logits"]
+        counts += np.bincount(logits.argmax(1).numpy(), minlength=NUM_CLASSES)
+        t_used += time.perf_counter() - t0
+        done += bs
+        if t_used >= seconds_budget * 0.6 or done >= 16:
+            break
+    fwd_per_s = done / t_used
+    return {"value": fwd_per_s / (N0 + N), "unit": "certified images/s", "cores": cores, "threads": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{done} of the {N0 + N} noisy ViT-G forwards of one certify (batch {bs}, fp32 PyTorch-CPU oracle), "
+                      f"{t_used:.1f} s; rate extrapolated to n0+n={N0 + N} forwards per image",
+            "forwards_per_s": fwd_per_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+    else:
+        torch.cuda.set_device(local)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    import certifiedgpt_amd as cg
+    dev = torch.device("cuda", local)
+    per_gpu = -(-max(N0, N) // world)                                  # largest shard of a _sample_noise call
+    clf = cg.HipClassifier(mode="vit_head", num_classes=NUM_CLASSES, max_batch=per_gpu, device=local)
+    clf.init_synthetic(seed=0)                                         # identical weights on every rank
+    smooth = cg.Smooth(clf, NUM_CLASSES, SIGMA, seed=42)
+    images = synthetic_images(args.steps + args.warmup, dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    results = []
+    for i in range(args.warmup):
+        results.append(smooth.certify(images[i], N0, N, ALPHA, per_gpu))
+    torch.cuda.synchronize()
+    clf.profile_read(0)
+    clf.profile(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        results.append(smooth.certify(images[args.warmup + i], N0, N, ALPHA, per_gpu))
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    clf.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fc1_ms, fc1_flops, fc1_n = clf.profile_read(1)
+    all_ms, all_flops, all_n = clf.profile_read(0)
+
+    if rank == 0:
+        value = args.steps / elapsed
+        fc1_tflops = fc1_flops / (fc1_ms * 1e-3) / 1e12 if fc1_ms > 0 else 0.0
+        all_tflops = all_flops / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
+        line = {
+            "metric": "certified images/sec (N=100, sigma=0.5)", "value": value, "unit": "certified images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "EVA-ViT-G encoder + ln_vision(CLS) + Linear head, random-init weights, 224x224 synthetic "
+                                   "image, Smooth.certify n0=100 n=100 alpha=0.001 sigma=0.5 (BASELINE configs[1])",
+                       "n0": N0, "n": N, "alpha": ALPHA, "sigma": SIGMA, "num_classes": NUM_CLASSES,
+                       "batch_size_per_gpu": per_gpu, "forwards_per_image": N0 + N,
+                       "parallelism": f"sample-sharded x{world}, one int64[{NUM_CLASSES}] all-reduce per _sample_noise"},
+            "forwards_per_s": value * (N0 + N),
+            "vit_tflops_end_to_end": value * (N0 + N) * F_VIT / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel<EPI_F16_GELU> (ViT MLP fc1, M=batch*257, N=6144, K=1408)",
+                         "achieved": fc1_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fc1_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": fc1_n, "avg_launch_ms": fc1_ms / max(fc1_n, 1),
+                         "flop_per_launch": fc1_flops / max(fc1_n, 1),
+                         "all_gemms": {"achieved": all_tflops, "frac": all_tflops / MFMA_PEAK_TFLOPS, "launches": all_n,
+                                       "total_ms": all_ms}},
+            "results_sample": [[int(l), float(r)] for l, r in results[-3:]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(clf, images[0])
+                line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            except Exception as e:  # the CPU leg must never void the GPU measurement
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    clf.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

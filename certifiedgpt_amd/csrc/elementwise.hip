@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ s
     float4 px = *reinterpret_cast<const float4*>(src + (NOISE ? 0 : (int64_t)b * 3 * img * img) + e);
     if (NOISE) {
         const float4 z = normal4(seed, (uint64_t)(first_sample + b), (uint32_t)grp, 0u);
-        px.x += sigma * z.x; px.y += sigma * z.y; px.z += sigma * z.z; px.w += sigma * z.w;
+        // explicit fma: the fused path and cgpt_noise_batch must round identically (bit-identical votes)
+        px.x = __fmaf_rn(sigma, z.x, px.x); px.y = __fmaf_rn(sigma, z.y, px.y);
+        px.z = __fmaf_rn(sigma, z.z, px.z); px.w = __fmaf_rn(sigma, z.w, px.w);
     }
     const int pw = img / ps;
     const int py = y / ps, iy = y - py * ps;
@@ -111,9 +113,10 @@ __global__ __launch_bounds__(256) void noise_batch_kernel(const float* __restric
     if (e + 3 < chw && (chw & 3) == 0) {
         const float4 px = *reinterpret_cast<const float4*>(x + e);
         *reinterpret_cast<float4*>(out + b * chw + e) =
-            make_float4(px.x + sigma * zz[0], px.y + sigma * zz[1], px.z + sigma * zz[2], px.w + sigma * zz[3]);
+            make_float4(__fmaf_rn(sigma, zz[0], px.x), __fmaf_rn(sigma, zz[1], px.y), __fmaf_rn(sigma, zz[2], px.z),
+                        __fmaf_rn(sigma, zz[3], px.w));
     } else {
-        for (int k = 0; k < 4 && e + k < chw; ++k) out[b * chw + e + k] = x[e + k] + sigma * zz[k];
+        for (int k = 0; k < 4 && e + k < chw; ++k) out[b * chw + e + k] = __fmaf_rn(sigma, zz[k], x[e + k]);
     }
 }
 

@@ -1,0 +1,175 @@
+"""GPU unit tests of the raw HIP kernels through the C-ABI (include/cgpt.h), each against a plain PyTorch fp32
+reference of the same op.  Failures print where the first mismatches are, so one gpurun round trip is enough to
+locate an indexing bug."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import certifiedgpt_amd as cg
+from certifiedgpt_amd import _lib
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ru(v, m):
+    return (v + m - 1) // m * m
+
+
+def report(name, got, ref, tol):
+    err = (got - ref).abs()
+    bad = err > tol
+    if bad.any():
+        idx = bad.nonzero()[:8].tolist()
+        rows = sorted(set(i[0] for i in bad.nonzero().tolist()))[:16]
+        msg = (f"{name}: {int(bad.sum())}/{bad.numel()} mismatches > {tol}; max err {float(err.max()):.4g}; "
+               f"first idx {idx}; got {[float(got[tuple(i)]) for i in idx[:4]]} ref {[float(ref[tuple(i)]) for i in idx[:4]]}; "
+               f"bad rows {rows}")
+        pytest.fail(msg)
+
+
+def run_gemm(M, N, K, bias=True, seed=0, asym=False):
+    L = cg.lib()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    Mp, Np = ru(M, 128), ru(N, 128)
+    A = torch.zeros(Mp, K, dtype=torch.float16)
+    W = torch.zeros(Np, K, dtype=torch.float16)
+    if asym:   # A = I (first K rows), asymmetric W: catches swapped row/col maps (cdna guide section 3)
+        A[:min(M, K), :] = torch.eye(K, dtype=torch.float16)[:min(M, K)]
+        W[:N] = (torch.arange(N)[:, None] * 0.5 + torch.arange(K)[None, :] * 0.01).half()
+    else:
+        A[:M] = (torch.randn(M, K, generator=g) * 0.5).half()
+        W[:N] = (torch.randn(N, K, generator=g) * 0.5).half()
+    b = torch.randn(N, generator=g) if bias else None
+    Ad, Wd = A.to(DEV), W.to(DEV)
+    bd = b.to(DEV) if bias else None
+    Cd = torch.full((M, N), float("nan"), device=DEV)
+    _lib.check(L.cgpt_gemm_f16(P(Ad), K, P(Wd), K, P(bd) if bias else None, P(Cd), N, M, N, K, stream()))
+    torch.cuda.synchronize()
+    ref = A[:M].float() @ W[:N].float().t()
+    if bias:
+        ref = ref + b
+    return Cd.cpu(), ref
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 192), (1, 200, 64), (257, 1408, 1408), (513, 640, 6144)])
+def test_gemm_matches_fp32_reference(M, N, K):
+    got, ref = run_gemm(M, N, K, seed=M + N + K)
+    report(f"gemm {M}x{N}x{K}", got, ref, 1e-3 + 1e-4 * float(ref.abs().max()))
+
+
+def test_gemm_identity_asymmetric():
+    got, ref = run_gemm(128, 256, 128, bias=False, asym=True)
+    report("gemm A=I asym W", got, ref, 1e-2)
+
+
+def test_gemm_large_shape_property():
+    # BASELINE shape fc2: M = 100*257 rows, K = 6144, N = 1408 -- checked on a strided sample of rows
+    L = cg.lib()
+    M, N, K = 25700, 1408, 6144
+    g = torch.Generator(device=DEV).manual_seed(1)
+    A = (torch.randn(ru(M, 128), K, device=DEV, generator=g) * 0.3).half()
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).half()
+    Cd = torch.empty(M, N, device=DEV)
+    _lib.check(L.cgpt_gemm_f16(P(A), K, P(W), K, None, P(Cd), N, M, N, K, stream()))
+    rows = torch.arange(0, M, 97, device=DEV)
+    ref = A[rows].float() @ W.float().t()
+    report("gemm fc2-shape", Cd[rows].cpu(), ref.cpu(), 5e-3)
+    # linearity: the same GEMM on 2*A gives exactly 2*C (power-of-two scaling is exact in fp16/fp32)
+    C2 = torch.empty(M, N, device=DEV)
+    A2 = (A * 2).contiguous()
+    _lib.check(L.cgpt_gemm_f16(P(A2), K, P(W), K, None, P(C2), N, M, N, K, stream()))
+    assert torch.equal(C2, Cd * 2)
+
+
+def attn_ref(q, k, v, heads, hd, scale):
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    qh = q.float().view(B, Tq, heads, hd).permute(0, 2, 1, 3)
+    kh = k.float().view(B, Tk, heads, hd).permute(0, 2, 1, 3)
+    vh = v.float().view(B, Tk, heads, hd).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, Tq, heads * hd)
+
+
+@pytest.mark.parametrize("B,heads,hd,Tq,Tk", [(3, 2, 88, 257, 257), (2, 16, 88, 257, 257), (2, 2, 88, 17, 17),
+                                               (3, 12, 64, 32, 257), (2, 12, 64, 32, 32), (2, 2, 64, 8, 17),
+                                               (1, 2, 64, 8, 8), (1, 1, 88, 1, 1)])
+def test_attention_matches_fp32_reference(B, heads, hd, Tq, Tk):
+    L = cg.lib()
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Tq + Tk)
+    D = heads * hd
+    ldq = ldkv = ru(D, 8)
+    q = torch.randn(B, Tq, ldq, generator=g).half()
+    k = torch.randn(B, Tk, ldkv, generator=g).half()
+    v = torch.randn(B, Tk, ldkv, generator=g).half()
+    # one spiky query/key pair: softmax must stay finite with a dominant logit
+    q[0, 0, :hd] *= 6
+    k[0, Tk - 1, :hd] = q[0, 0, :hd] * 0.5
+    scale = hd ** -0.5
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    od = torch.full((B, Tq, ldq), float("nan"), device=DEV, dtype=torch.float16)
+    _lib.check(L.cgpt_attention_f16(P(qd), ldq, P(kd), P(vd), ldkv, P(od), ldq, B, heads, hd, Tq, Tk, scale, stream()))
+    torch.cuda.synchronize()
+    ref = attn_ref(q[..., :D], k[..., :D], v[..., :D], heads, hd, scale)
+    got = od.cpu().float()[..., :D]
+    report(f"attention B{B} h{heads} d{hd} {Tq}x{Tk}", got.reshape(B * Tq, D), ref.reshape(B * Tq, D), 6e-3)
+
+
+@pytest.mark.parametrize("rows,D", [(5, 176), (7, 128), (33, 768), (257, 1408), (3, 4096)])
+def test_layernorm_matches_torch(rows, D):
+    L = cg.lib()
+    g = torch.Generator(device="cpu").manual_seed(D)
+    x = torch.randn(rows, D, generator=g) * 3 + 1
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ld16 = ru(D, 64)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y16 = torch.zeros(rows, ld16, dtype=torch.float16, device=DEV)
+    y32 = torch.zeros(rows, D, device=DEV)
+    for eps in (1e-6, 1e-12):
+        _lib.check(L.cgpt_layernorm(P(xd), D, P(wd), P(bd), eps, P(y16), ld16, P(y32), D, rows, D, stream()))
+        ref = torch.nn.functional.layer_norm(x, (D,), w, b, eps)
+        report(f"layernorm f32 {rows}x{D}", y32.cpu(), ref, 2e-5 * max(1.0, float(ref.abs().max())))
+        report(f"layernorm f16 {rows}x{D}", y16.cpu().float()[:, :D], ref, 2e-3 * max(1.0, float(ref.abs().max())))
+    assert float(y16[:, D:].abs().max()) == 0.0 if ld16 > D else True
+
+
+def test_noise_stream_matches_oracle_and_is_shard_independent():
+    x = torch.randn(3, 56, 56)
+    xd = x.to(DEV)
+    full = cg.noise_batch(xd, 5, 6, 0.5, 42)
+    torch.cuda.synchronize()
+    ref = x.numpy()[None] + np.float32(0.5) * philox.noise_batch(42, 5, 6, (3, 56, 56))
+    assert np.abs(full.cpu().numpy() - ref).max() < 5e-6          # fp32 vs float64 transcendental rounding only
+    part = cg.noise_batch(xd, 7, 3, 0.5, 42)                      # samples 7,8,9 == rows 2,3,4 of `full`
+    assert torch.equal(part, full[2:5])                           # bit-identical for any batching / sharding
+    z = (cg.noise_batch(torch.zeros(3, 224, 224, device=DEV), 0, 8, 1.0, 7)).flatten()
+    assert abs(float(z.mean())) < 3e-3 and abs(float(z.std()) - 1) < 3e-3
+    assert abs(float((z ** 3).mean())) < 1e-2 and abs(float((z ** 4).mean()) - 3) < 3e-2
+    z2 = cg.noise_batch(torch.zeros(3, 224, 224, device=DEV), 0, 8, 1.0, 8).flatten()
+    assert abs(float((z * z2).mean())) < 3e-3                     # different seeds are uncorrelated
+
+
+def test_vote_first_max_and_accumulates():
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for K in (2, 10, 63, 64, 65, 1000):
+        logits = torch.randn(333, K, generator=g)
+        logits[5] = 1.0                                           # full tie -> class 0
+        logits[6, K - 1] = logits[6, 0] = 9.0                     # two maxima -> the first one
+        ld = logits.to(DEV)
+        counts = torch.zeros(K, dtype=torch.int64, device=DEV)
+        cg.vote(ld, counts)
+        cg.vote(ld, counts)                                       # accumulates
+        ref = 2 * torch.bincount(torch.argmax(logits, dim=1), minlength=K)
+        assert torch.equal(counts.cpu(), ref), (K, counts.cpu().tolist()[:10], ref.tolist()[:10])

@@ -1,0 +1,193 @@
+"""GPU parity tests proper: the HIP path through the C-ABI against (a) golden outputs of the reference's own
+eva_vit.py / Qformer.py classes (tests/golden/model_golden.npz), (b) the fp32 CPU oracle on identical inputs and
+weights, (c) size-independent properties at BASELINE.json's full ViT-G size.
+
+Tolerances.  The reference's precision contract on a HIP device is fp16 weights + fp16 autocast
+(eva_vit.py:407-414, base_model.py:141-142); this path uses fp16 MFMA operands with fp32 accumulation and an fp32
+residual stream, the oracle is pure fp32.  Activations therefore agree to ~1e-2 relative (written per test);
+the vote / abstain / radius logic given counts is bit-exact / 1e-9 (tests/test_capi_cpu.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import certifiedgpt_amd as cg
+from oracle import model_oracle as mo, smooth_oracle as so, philox
+from conftest import GOLDEN
+from gpu_util import DEV, tiny_pair, make_classifier, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_weights_round_trip_and_names():
+    clf, p16, params, cfg = tiny_pair(mo.MODE_ENCODE_IMG)
+    assert clf.weight_names() == list(mo.param_shapes(cfg).keys())       # same registry, same order as the oracle
+    for name in ("visual_encoder.blocks.1.attn.qkv.weight", "visual_encoder.blocks.0.attn.v_bias", "visual_encoder.pos_embed",
+                 "Qformer.bert.encoder.layer.0.crossattention.self.value.weight",
+                 "Qformer.bert.encoder.layer.1.attention.self.key.bias", "query_tokens", "head.weight"):
+        got = clf.get_weight(name)
+        assert np.array_equal(got, p16[name].numpy().reshape(-1)), name    # exactly fp16-rounded matrices / fp32 vectors
+    import ctypes as C
+    a = np.zeros(3, dtype=np.float32)
+    assert clf._L.cgpt_load_weight(clf._h, b"head.bias", a.ctypes.data_as(C.c_void_p), 3) == 1      # numel mismatch
+    assert clf._L.cgpt_load_weight(clf._h, b"no.such.weight", a.ctypes.data_as(C.c_void_p), 3) == 4  # not found
+    assert b"no.such.weight" in clf._L.cgpt_last_error()
+
+
+def test_tiny_model_matches_reference_goldens():
+    """Golden vectors = outputs of the reference's own VisionTransformer / BertEncoder classes."""
+    g = np.load(os.path.join(GOLDEN, "model_golden.npz"))
+    clf, p16, params, cfg = tiny_pair(mo.MODE_ENCODE_IMG, seed=int(g["seed"]))
+    x = torch.from_numpy(g["x"]).to(DEV)
+    clf(x)
+    n = x.shape[0]
+    for what, tol in (("vit_out", 1e-2), ("ln_vision", 1e-2), ("qformer", 2e-2), ("llama", 2e-2)):
+        e = rel_err(clf.activation(what, n), g[what])
+        assert e <= tol, (what, e)
+
+
+@pytest.mark.parametrize("mode", [mo.MODE_VIT_HEAD, mo.MODE_ENCODE_IMG])
+def test_tiny_model_matches_oracle_all_stages(mode):
+    clf, p16, params, cfg = tiny_pair(mode, max_batch=8)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    noisy = cg.noise_batch(x0, 0, 8, 0.5, 42)
+    logits = clf(noisy)
+    ref = mo.forward_all(p16, noisy.cpu(), cfg)
+    stages = ["vit_out"] + (["ln_vision", "qformer", "llama"] if mode == mo.MODE_ENCODE_IMG else [])
+    for what in stages:
+        e = rel_err(clf.activation(what, 8), ref[what])
+        assert e <= 1e-2, (what, e)
+    e = rel_err(logits, ref["logits"])
+    assert e <= 1e-2, ("logits", e)
+    # fused noise+im2col path == noise_batch followed by the plain im2col path, bit for bit
+    fused = clf.forward_logits(x0, 0, 8, 0.5, 42)
+    assert torch.equal(fused, logits)
+
+
+@pytest.mark.parametrize("mode", [mo.MODE_VIT_HEAD, mo.MODE_ENCODE_IMG])
+def test_smooth_matches_oracle_on_identical_noise(mode):
+    """Smooth.certify / predict on the GPU vs the line-for-line CPU restatement of the reference's Smooth fed with the
+    SAME noisy inputs (the GPU's own draws, exported) and the same weights.  Votes must agree on every sample whose
+    fp32 top-2 logit margin is decisive; label / abstain / radius given the counts are then exact."""
+    K = 10
+    clf, p16, params, cfg = tiny_pair(mode, num_classes=K, max_batch=16)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    sigma, seed, n0, n, alpha, bs = 0.25, 5, 24, 40, 0.05, 16
+
+    def gpu_noise(first, num, shape):                       # N(0,1) draws exactly as the GPU made them
+        nb = cg.noise_batch(torch.zeros(shape, device=DEV), first, num, 1.0, seed)
+        return nb.cpu().numpy()
+
+    oracle = so.SmoothOracle(mo.make_classifier(p16, cfg), K, sigma, gpu_noise)
+    s = cg.Smooth(clf, K, sigma, seed=seed)
+    # per-sample agreement
+    noisy = cg.noise_batch(x0, 0, n0 + n, sigma, seed)
+    ref_logits = mo.forward_all(p16, noisy.cpu(), cfg)["logits"]
+    got_logits = torch.cat([clf(noisy[i:i + 16]) for i in range(0, n0 + n, 16)]).cpu()
+    top2 = ref_logits.topk(2, dim=1).values
+    decisive = (top2[:, 0] - top2[:, 1]) > 2e-2 * ref_logits.abs().max()
+    agree = got_logits.argmax(1) == ref_logits.argmax(1)
+    assert bool(agree[decisive].all()), (int((~agree).sum()), int(decisive.sum()))
+    assert float(agree.float().mean()) >= 0.9
+    # counts: GPU hot loop vs CPU hot loop
+    c_sel = s._sample_noise(x0, n0, bs)
+    c_est = s._sample_noise(x0, n, bs)
+    oracle._cursor = 0
+    o_sel = oracle._sample_noise(x0.cpu().numpy(), n0, bs)
+    o_est = oracle._sample_noise(x0.cpu().numpy(), n, bs)
+    assert c_sel.sum() == n0 and c_est.sum() == n
+    flips = int(np.abs(c_sel - o_sel).sum() + np.abs(c_est - o_est).sum()) // 2
+    assert flips <= int((~decisive).sum()), (c_sel, o_sel, c_est, o_est)
+    # statistics on identical counts: exact decision, radius to 1e-9 (north star: 1e-3)
+    lab, rad = s.certify_from_counts(c_sel, c_est, n, alpha)
+    olab, orad = so.certify_from_counts(c_sel, c_est, n, alpha, sigma)
+    assert lab == olab and abs(rad - orad) <= 1e-9
+    assert s.predict_from_counts(c_est, alpha) == so.predict_from_counts(c_est, alpha)
+    # the public API end to end, reproducible after reset()
+    s.reset()
+    out1 = s.certify(x0, n0, n, alpha, bs)
+    s.reset()
+    out2 = s.certify(x0, n0, n, alpha, 7)                   # ragged last batch, different batch size: same counts
+    assert out1 == out2 == (lab, rad)
+    assert isinstance(out1[0], int) and isinstance(out1[1], float)
+    p = s.predict(x0, n, alpha, bs)
+    assert p == cg.Smooth.ABSTAIN or 0 <= p < K
+
+
+def test_generic_module_path_uses_hip_noise_and_vote():
+    """A base classifier that is an ordinary callable on PyTorch-ROCm (e.g. MiniGPT-4 + Vicuna): noise and vote are HIP."""
+    K = 5
+    w = torch.randn(K, 3 * 8 * 8, device=DEV)
+
+    class Lin:
+        def eval(self):
+            return self
+
+        def __call__(self, b):
+            return b.flatten(1) @ w.t()
+
+    x = torch.randn(3, 8, 8, device=DEV)
+    s = cg.Smooth(Lin(), K, 0.5, seed=3)
+    counts = s._sample_noise(x, 50, 16)
+    noisy = cg.noise_batch(x, 0, 50, 0.5, 3)
+    ref = torch.bincount((noisy.flatten(1) @ w.t()).argmax(1), minlength=K).cpu().numpy()
+    assert counts.tolist() == ref.tolist()
+
+
+# ------------------------------------------------------------------ BASELINE.json full size (ViT-G, 224x224)
+@pytest.fixture(scope="module")
+def vitg():
+    cfg = mo.Config(mode=mo.MODE_VIT_HEAD, num_classes=1000)
+    clf = make_classifier(cfg, max_batch=100)
+    clf.init_synthetic(seed=0)
+    yield clf, cfg
+    clf.close()
+
+
+def test_vitg_synthetic_init_follows_reference_law(vitg):
+    clf, cfg = vitg
+    w = clf.get_weight("visual_encoder.blocks.7.mlp.fc2.weight")
+    assert abs(w.std() - 0.02 / np.sqrt(16.0)) < 2e-4 and abs(w.mean()) < 1e-4       # / sqrt(2*layer_id), eva_vit.py:308-314
+    assert abs(clf.get_weight("visual_encoder.blocks.7.attn.qkv.weight").std() - 0.02) < 2e-4
+    assert np.all(clf.get_weight("visual_encoder.blocks.3.norm1.weight") == 1) and np.all(clf.get_weight("visual_encoder.blocks.3.mlp.fc1.bias") == 0)
+    # the device generator is the oracle's counter-based table (same tensor ids), up to fp32 transcendental rounding
+    tid = list(mo.param_shapes(cfg).keys()).index("visual_encoder.blocks.0.attn.proj.weight")
+    z = philox.normal_stream(0, tid, 4096, hi_word=1) * np.float32(0.02 / np.sqrt(2.0))
+    got = clf.get_weight("visual_encoder.blocks.0.attn.proj.weight")[:4096]
+    assert np.abs(got - z.astype(np.float16).astype(np.float32)).max() <= 2e-5
+
+
+def test_vitg_counts_invariant_to_batching_and_sharding(vitg):
+    """Size-independent property at BASELINE size (N=100, sigma=0.5): counts depend only on the global sample indices."""
+    clf, cfg = vitg
+    x = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    full = clf.sample_counts(x, 0, 100, 100, 0.5, 42)
+    assert int(full.sum()) == 100
+    b32 = clf.sample_counts(x, 0, 100, 32, 0.5, 42)                       # ragged batches 32,32,32,4
+    assert torch.equal(full, b32)
+    parts = torch.zeros_like(full)
+    for r in range(8):                                                    # the 8-GPU partition 13,13,13,13,12,12,12,12
+        lo, hi = cg.shard_range(100, r, 8)
+        clf.sample_counts(x, lo, hi - lo, 13, 0.5, 42, counts=parts)
+    assert torch.equal(full, parts)
+    other = clf.sample_counts(x, 100, 100, 100, 0.5, 42)                  # fresh indices: a different draw
+    assert int(other.sum()) == 100
+    logits = clf.forward_logits(x, 0, 100, 0.5, 42)
+    assert torch.isfinite(logits).all()
+    assert torch.equal(torch.bincount(logits.argmax(1), minlength=1000), full)
+
+
+def test_vitg_matches_oracle_on_two_samples(vitg):
+    """Full-size numerical check: 2 noisy samples through ViT-G on the GPU vs the fp32 CPU oracle with the device's weights."""
+    clf, cfg = vitg
+    x = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    noisy = cg.noise_batch(x, 0, 2, 0.5, 42)
+    logits = clf(noisy).cpu()
+    vit_gpu = clf.activation("vit_out", 2).cpu()
+    params = {n: torch.from_numpy(clf.get_weight(n)).reshape(s) for n, s in mo.param_shapes(cfg).items()}
+    torch.set_num_threads(os.cpu_count() or 1)
+    ref = mo.forward_all(params, noisy.cpu(), cfg)
+    e_vit = rel_err(vit_gpu, ref["vit_out"])
+    e_log = rel_err(logits, ref["logits"])
+    assert e_vit <= 2e-2 and e_log <= 2e-2, (e_vit, e_log)
