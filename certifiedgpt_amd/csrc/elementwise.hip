@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ s
         // explicit fma: the fused path and cgpt_noise_batch must round identically (bit-identical votes)
         px.x = __fmaf_rn(sigma, z.x, px.x); px.y = __fmaf_rn(sigma, z.y, px.y);
         px.z = __fmaf_rn(sigma, z.z, px.z); px.w = __fmaf_rn(sigma, z.w, px.w);
+        // keep the fp32 sum as its own value: otherwise hipcc fuses fma + f16 convert into v_fma_mixlo_f16 (ONE
+        // rounding), while the reference rounds batch + noise to fp32 first and autocast then casts to fp16.
+        asm volatile("" : "+v"(px.x), "+v"(px.y), "+v"(px.z), "+v"(px.w));
     }
     const int pw = img / ps;
     const int py = y / ps, iy = y - py * ps;
