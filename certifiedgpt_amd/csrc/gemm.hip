@@ -15,6 +15,8 @@
 // and written to the other LDS buffer after them; one barrier per K-tile.
 // Block -> tile map: XCD-contiguous chunks (blocks b and b+8 share an XCD) and, inside a chunk, groups of 8
 // tile-rows walked column-major so that the 64 tiles resident on an XCD share 8 A-strips and 8 W-strips in L2.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace cgpt {
@@ -27,7 +29,53 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GROUP_M = 8;
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact-erf GELU (nn.GELU default, eva_vit.py:50,61) = x * Phi(x), with erf from Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the fp16 rounding of the output): Phi(|x|) = 1 - 0.5 * P(t) * exp(-x^2/2),
+// t = 1/(1 + 0.3275911 |x|/sqrt2).  ~17 VALU ops instead of ocml erff's ~40: the fc1 epilogue runs 128 of these per lane.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);       // exp(-x^2/2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
+    float pl = fmaf(t, 1.061405429f, -1.453152027f);
+    pl = fmaf(t, pl, 1.421413741f);
+    pl = fmaf(t, pl, -0.284496736f);
+    pl = fmaf(t, pl, 0.254829592f);
+    const float h = 0.5f * pl * t * e;                                               // 0.5 * erfc(|x|/sqrt2)
+    const float phi = x >= 0.0f ? 1.0f - h : h;
+    return x * phi;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float v) {
+    if constexpr (EPI == EPI_F16) {
+        reinterpret_cast<half_t*>(p.out)[(int64_t)m * p.ldo + n] = (half_t)v;
+    } else if constexpr (EPI == EPI_F16_GELU) {
+        reinterpret_cast<half_t*>(p.out)[(int64_t)m * p.ldo + n] = (half_t)gelu_erf(v);
+    } else if constexpr (EPI == EPI_F32) {
+        reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + n] = v;
+    } else if constexpr (EPI == EPI_RESID) {
+        v += p.aux[(int64_t)m * p.ldaux + n];
+        reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + n] = v;
+    } else {  // EPI_PATCH
+        const int b = m / p.patches, pp = m - b * p.patches;
+        v += p.aux[(int64_t)(1 + pp) * p.ldaux + n];
+        reinterpret_cast<float*>(p.out)[((int64_t)b * (p.patches + 1) + 1 + pp) * p.ldo + n] = v;
+    }
+}
+
+// Block -> tile map shared by both kernels (speed only): XCD-contiguous chunks, then groups of GROUP_M tile-rows
+// walked column-major.
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = t / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_grp = t - grp * per_group;
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
@@ -42,19 +90,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
     // ---- block -> tile (speed only; any map is correct)
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.N + BN - 1) / BN;
-    int t;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int per_group = GROUP_M * tiles_n;
-    const int grp = t / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int in_grp = t - grp * per_group;
-    const int tm = first_m + in_grp % gsz;
-    const int tn = in_grp / gsz;
+    int tm, tn;
+    tile_of_block(tiles_m, tiles_n, tm, tn);
 
     // ---- staging: thread -> (row tid/8 + 32*i, 16-byte chunk tid%8)
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
@@ -141,31 +178,167 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m_base + i * 16 + r;
                 if (m >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                if constexpr (EPI == EPI_F16) {
-                    reinterpret_cast<half_t*>(p.out)[(int64_t)m * p.ldo + n] = (half_t)v;
-                } else if constexpr (EPI == EPI_F16_GELU) {
-                    reinterpret_cast<half_t*>(p.out)[(int64_t)m * p.ldo + n] = (half_t)gelu_erf(v);
-                } else if constexpr (EPI == EPI_F32) {
-                    reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + n] = v;
-                } else if constexpr (EPI == EPI_RESID) {
-                    v += p.aux[(int64_t)m * p.ldaux + n];
-                    reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + n] = v;
-                } else {  // EPI_PATCH
-                    const int b = m / p.patches, pp = m - b * p.patches;
-                    v += p.aux[(int64_t)(1 + pp) * p.ldaux + n];
-                    reinterpret_cast<float*>(p.out)[((int64_t)b * (p.patches + 1) + 1 + pp) * p.ldo + n] = v;
-                }
+                epilogue_store<EPI>(p, m, n, acc[i][j][r] + bias);
             }
         }
     }
 }
 
+// ------------------------------------------------------------------------------------------------ v2
+// 256 x BN x 64 tile, 8 waves, operands staged straight into LDS by global_load_lds_dwordx4 (no VGPR round
+// trip, no ds_write: the register-staged v1 kernel is bound by the ~79 B/clk ds_write_b128 path).
+// One wave-instruction writes 1 KiB = 8 tile rows x 128 B, lane l -> row l>>3, 16-byte slot l&7; the XOR swizzle
+// therefore goes on the per-lane SOURCE address (slot c' of row r receives global chunk c' ^ ((r>>1)&7)) and the
+// fragment reads apply the same involution (cdna guide section 5.4 rule 21).
+// Two LDS stages; the loads of K-tile t+1 are issued before the MFMAs of K-tile t and retired by the
+// vmcnt(0) + barrier that ends the iteration.
+//   BN = 256: waves 2(M) x 4(N), wave tile 128x64 (acc 128 VGPRs), 12 ds_read_b128 per 32 MFMAs, LDS 128 KiB
+//   BN = 128: waves 4(M) x 2(N), wave tile  64x64 (acc  64 VGPRs), 16 ds_read_b128 per 32 MFMAs, LDS  96 KiB
+template <int EPI, int BN_>
+__global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
+    constexpr int BM2 = 256;
+    constexpr int WN = (BN_ == 256) ? 4 : 2, WM = 8 / WN;
+    constexpr int TM = BM2 / WM / 16, TN = BN_ / WN / 16;
+    constexpr int A_ELEMS = BM2 * BK, B_ELEMS = BN_ * BK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int A_INSTR = BM2 / 64, B_INSTR = BN_ / 64;          // 1-KiB glds pieces per wave per stage
+    extern __shared__ __attribute__((aligned(16))) half_t smem2[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int r15 = lane & 15, g = lane >> 4;
+
+    const int tiles_m = (p.M + BM2 - 1) / BM2;
+    const int tiles_n = (p.N + BN_ - 1) / BN_;
+    int tm, tn;
+    tile_of_block(tiles_m, tiles_n, tm, tn);
+
+    // ---- staging sources: piece i of this wave covers tile rows wave*(rows/8) + i*8 .. +7
+    const int lr = lane >> 3, cpos = lane & 7;
+    const half_t* a_src[A_INSTR];
+    const half_t* b_src[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = wave * (BM2 / 8) + i * 8 + lr;
+        a_src[i] = p.A + (int64_t)(tm * BM2 + r) * p.lda + ((cpos ^ ((r >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = wave * (BN_ / 8) + i * 8 + lr;
+        b_src[i] = p.W + (int64_t)(tn * BN_ + r) * p.ldw + ((cpos ^ ((r >> 1) & 7)) << 3);
+    }
+    auto stage_load = [&](int stage, int kt) {
+        half_t* sa = smem2 + stage * STAGE + wave * (BM2 / 8) * BK;
+        half_t* sb = smem2 + stage * STAGE + A_ELEMS + wave * (BN_ / 8) * BK;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 8 * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sb + i * 8 * BK), 16, 0, 0);
+    };
+
+    const int sw = (r15 >> 1) & 7;
+    const int k_off0 = ((g ^ sw) << 3), k_off1 = (((4 + g) ^ sw) << 3);
+    const int a_rd = (wr * (BM2 / WM) + r15) * BK;
+    const int b_rd = A_ELEMS + (wc * (BN_ / WN) + r15) * BK;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage_load(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage_load((kt + 1) & 1, kt + 1);
+        const half_t* st = smem2 + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ko = ks ? k_off1 : k_off0;
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + ko);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK + ko);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int m_base = tm * BM2 + wr * (BM2 / WM) + 4 * g;
+    const int n_base = tn * BN_ + wc * (BN_ / WN) + r15;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + j * 16;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + i * 16 + r;
+                if (m >= p.M) continue;
+                epilogue_store<EPI>(p, m, n, acc[i][j][r] + bias);
+            }
+        }
+    }
+}
+
+template <int EPI, int BN_>
+hipError_t launch_v2(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds_bytes = 2 * (256 + BN_) * BK * (int)sizeof(half_t);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_f16_kernel<EPI, BN_>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + BN_ - 1) / BN_);
+    hipLaunchKernelGGL((gemm2_f16_kernel<EPI, BN_>), dim3(tiles), dim3(512), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+template <int BN_>
+hipError_t launch_v2_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
+    switch (epilogue) {
+        case EPI_F16: return launch_v2<EPI_F16, BN_>(p, stream);
+        case EPI_F16_GELU: return launch_v2<EPI_F16_GELU, BN_>(p, stream);
+        case EPI_F32: return launch_v2<EPI_F32, BN_>(p, stream);
+        case EPI_RESID: return launch_v2<EPI_RESID, BN_>(p, stream);
+        case EPI_PATCH: return launch_v2<EPI_PATCH, BN_>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 }  // namespace
+
+int g_gemm_kernel = 0;
 
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
         return hipErrorInvalidValue;
+    // Kernel choice (speed only).  v2 needs A readable for round_up(M,256) rows and W for round_up(N,BN) rows: the
+    // library's buffers are padded to 256 rows; weights to 128 rows, so BN=256 only when N % 256 == 0.
+    const int force = g_gemm_kernel;   // 0 auto, 1 v1 (128x128), 2 v2 BN=256, 3 v2 BN=128  (cgpt_set_option)
+    if (force == 2 && (p.N % 256) == 0) return launch_v2_epi<256>(epilogue, p, stream);
+    if (force == 3 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
+    if (force == 0 && p.M >= 1024) {
+        // measured on MI355X at M = 25700 / 3341 (profiles/r01/gemm_ab_*.txt): 256x256 wins whenever it tiles N exactly;
+        // 256x128 wins for N % 256 != 0 except the long-K, large-M fc2 shape where two 4-wave blocks per CU hide more.
+        if ((p.N % 256) == 0) return launch_v2_epi<256>(epilogue, p, stream);
+        if ((p.N % 128) == 0 && !(p.K > 2048 && p.M >= 8192)) return launch_v2_epi<128>(epilogue, p, stream);
+    }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);
     switch (epilogue) {

@@ -9,7 +9,7 @@ typedef _Float16 half_t;
 
 // ---------------------------------------------------------------------------------------------- GEMM
 // C = A[M,K] * W[N,K]^T with a fused epilogue.  A/W are fp16, K contiguous.  Requirements (the library's
-// own buffers satisfy them): K % 64 == 0; A readable for round_up(M,128) rows; W readable for
+// own buffers satisfy them): K % 64 == 0; A readable for round_up(M,256) rows; W readable for
 // round_up(N,128) rows; pad K-columns of A and W hold zeros.
 enum GemmEpilogue {
     EPI_F16 = 0,        // out_f16[m,n] = acc + bias[n]
@@ -28,6 +28,7 @@ struct GemmParams {
     int patches;                  // EPI_PATCH: P (patches per image)
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
+extern int g_gemm_kernel;   // kernel override for A/B measurements: 0 auto, 1 v1, 2 v2<256>, 3 v2<128>
 
 // ---------------------------------------------------------------------------------------- attention
 // O[b,q,h*hd + d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d]   (eva_vit.py:133-150,

@@ -7,7 +7,7 @@
 //              fp32 vectors for biases / LayerNorm affine / cls_token / pos_embed / query_tokens.
 //   workspace  sized for max_batch samples: im2col A [nb*P][640] fp16, residual stream [nb*T][D] fp32,
 //              LayerNorm output / attention output [nb*T][D] fp16, qkv [nb*T][3D] fp16, MLP hidden [nb*T][6144] fp16, ...
-//              Row counts are padded to 128 and K-dims to 64 so every GEMM tile load is in bounds; pad columns
+//              Row counts are padded to 256 and K-dims to 64 so every GEMM tile load is in bounds; pad columns
 //              are zero at allocation and never written.
 #include <hip/hip_runtime.h>
 
@@ -135,13 +135,13 @@ cgpt_status add_vec(cgpt_model* m, const std::string& name, int64_t n, int init,
 // activation buffers
 cgpt_status new_act16(cgpt_model* m, int64_t rows, int64_t cols, half_t** out) {
     void* p;
-    CGCHK(dev_alloc(m, (size_t)ru(rows, 128) * ru(cols, 64) * sizeof(half_t), &p));
+    CGCHK(dev_alloc(m, (size_t)ru(rows, 256) * ru(cols, 64) * sizeof(half_t), &p));
     *out = (half_t*)p;
     return CGPT_OK;
 }
 cgpt_status new_act32(cgpt_model* m, int64_t rows, int64_t cols, float** out) {
     void* p;
-    CGCHK(dev_alloc(m, (size_t)ru(rows, 128) * cols * sizeof(float), &p));
+    CGCHK(dev_alloc(m, (size_t)ru(rows, 256) * cols * sizeof(float), &p));
     *out = (float*)p;
     return CGPT_OK;
 }
@@ -590,6 +590,17 @@ cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes,
     if (!logits_dev || !counts_dev || num < 0 || num_classes < 1) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_vote: bad argument");
     HIPCHK(launch_vote(logits_dev, num_classes, num, num_classes, counts_dev, (hipStream_t)stream));
     return CGPT_OK;
+}
+
+cgpt_status cgpt_set_option(const char* key, int32_t value) {
+    if (!key) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: null key");
+    const std::string k(key);
+    if (k == "gemm_kernel") {
+        if (value < 0 || value > 3) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_kernel must be 0..3");
+        g_gemm_kernel = value;
+        return CGPT_OK;
+    }
+    return cgpt_fail(CGPT_ERR_NOT_FOUND, "cgpt_set_option: unknown option '" + k + "'");
 }
 
 cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on) {

@@ -158,10 +158,15 @@ double cgpt_norm_ppf(double p);
 cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on);
 cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
 
+/* Process-wide tuning knobs for A/B measurements (never needed for correctness):
+ *   "gemm_kernel": 0 = automatic choice, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS kernel
+ *                  (N % 256 == 0 only), 3 = 256x128 direct-to-LDS kernel (N % 128 == 0 only). */
+cgpt_status cgpt_set_option(const char* key, int32_t value);
+
 /* ---- raw kernels exported for unit tests and reuse (all fp16 operands are IEEE binary16) ----
  * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) ; A row stride lda, W row stride ldw (elements), fp32 accumulate.
- * Requirements: M%256==0 is NOT required, but A must be readable for ceil(M/128)*128 rows;
- * K%64==0, N%128==0 (pad with zeros; the library's own buffers always are).  out is fp32 [M,ldc]. */
+ * Requirements: A must be readable for ceil(M/256)*256 rows and W for ceil(N/128)*128 rows (zero padded; the
+ * library's own buffers always are); K%64==0.  out is fp32 [M,ldc]. */
 cgpt_status cgpt_gemm_f16(const void* A_dev, int64_t lda, const void* W_dev, int64_t ldw, const float* bias_dev,
                           float* C_dev, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
 /* softmax(scale * Q K^T) V per (batch, head): Q [B,Tq,ldq] K,V [B,Tk,ldkv] fp16 with head h at column h*head_dim;

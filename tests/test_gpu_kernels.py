@@ -42,7 +42,7 @@ def report(name, got, ref, tol):
 def run_gemm(M, N, K, bias=True, seed=0, asym=False):
     L = cg.lib()
     g = torch.Generator(device="cpu").manual_seed(seed)
-    Mp, Np = ru(M, 128), ru(N, 128)
+    Mp, Np = ru(M, 256), ru(N, 128)
     A = torch.zeros(Mp, K, dtype=torch.float16)
     W = torch.zeros(Np, K, dtype=torch.float16)
     if asym:   # A = I (first K rows), asymmetric W: catches swapped row/col maps (cdna guide section 3)
@@ -63,14 +63,27 @@ def run_gemm(M, N, K, bias=True, seed=0, asym=False):
     return Cd.cpu(), ref
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 192), (1, 200, 64), (257, 1408, 1408), (513, 640, 6144)])
-def test_gemm_matches_fp32_reference(M, N, K):
-    got, ref = run_gemm(M, N, K, seed=M + N + K)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 192), (1, 200, 64), (257, 1408, 1408), (513, 640, 6144),
+                                   (1024, 512, 128), (2000, 384, 192), (1300, 768, 1408), (1029, 256, 64)])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+def test_gemm_matches_fp32_reference(M, N, K, kernel):
+    L = cg.lib()
+    _lib.check(L.cgpt_set_option(b"gemm_kernel", kernel))
+    try:
+        got, ref = run_gemm(M, N, K, seed=M + N + K)
+    finally:
+        _lib.check(L.cgpt_set_option(b"gemm_kernel", 0))
     report(f"gemm {M}x{N}x{K}", got, ref, 1e-3 + 1e-4 * float(ref.abs().max()))
 
 
-def test_gemm_identity_asymmetric():
-    got, ref = run_gemm(128, 256, 128, bias=False, asym=True)
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_gemm_identity_asymmetric(kernel):
+    L = cg.lib()
+    _lib.check(L.cgpt_set_option(b"gemm_kernel", kernel))
+    try:
+        got, ref = run_gemm(256, 256, 128, bias=False, asym=True)
+    finally:
+        _lib.check(L.cgpt_set_option(b"gemm_kernel", 0))
     report("gemm A=I asym W", got, ref, 1e-2)
 
 
@@ -79,7 +92,7 @@ def test_gemm_large_shape_property():
     L = cg.lib()
     M, N, K = 25700, 1408, 6144
     g = torch.Generator(device=DEV).manual_seed(1)
-    A = (torch.randn(ru(M, 128), K, device=DEV, generator=g) * 0.3).half()
+    A = (torch.randn(ru(M, 256), K, device=DEV, generator=g) * 0.3).half()
     W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).half()
     Cd = torch.empty(M, N, device=DEV)
     _lib.check(L.cgpt_gemm_f16(P(A), K, P(W), K, None, P(Cd), N, M, N, K, stream()))
