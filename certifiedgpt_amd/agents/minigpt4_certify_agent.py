@@ -1,0 +1,122 @@
+"""Certify agent -- the reference ships `agents/minigpt4_certify_agent.py` as an EMPTY file, so the
+shape here is inferred from the plugin contract (launch.py:97-107) and from the sibling eval agent
+(agents/minigpt4_eval_agent.py:52-124): build the classifier, loop over (image, label) samples, call Smooth.certify,
+log one line per sample (idx, label, predict, radius, correct, time -- the format of Cohen et al.'s certify.py that
+`Smooth` comes from), then report certified accuracy at a few radii.
+
+Config (a plain dict or any mapping; the reference's YAMLs define no smoothing keys, so these are build-side):
+    run:   {agent: image_text_certify, output_dir: ..., seed: 0,
+            smoothing: {sigma: 0.5, n0: 100, n: 100, alpha: 0.001, batch_size: 100, num_classes: 1000, radii: [0.25, 0.5, 1.0]}}
+    model: {mode: vit_head | encode_img, weights: <path to a torch state_dict saved with torch.save> | null, dims: {...}}
+    data:  {num_images: 10, seed: 1234}      # synthetic CLIP-normalised images unless `dataset` is passed to the agent
+"""
+import json
+import os
+import time
+
+import torch
+
+from ..smoothing import Smooth
+from .base import BaseAgent
+from .registry import registry
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)    # processors/base_processor.py:18-20
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def synthetic_dataset(num_images, img_size, seed, device, num_classes):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+    for i in range(num_images):
+        u = torch.rand(3, img_size, img_size, generator=g)
+        yield ((u - mean) / std).to(device), int(torch.randint(0, num_classes, (1,), generator=g))
+
+
+class CertifyLoop:
+    """Engine-agnostic loop: usable as a mixin with the reference's own BaseAgent."""
+
+    def certify_dataset(self, sm_cfg, dataset, smooth, log_path=None, mode="certify"):
+        self.records = []
+        f = open(log_path, "w") if log_path else None
+        header = "idx\tlabel\tpredict\tradius\tcorrect\ttime" if mode == "certify" else "idx\tlabel\tpredict\tcorrect\ttime"
+        if f:
+            print(header, file=f, flush=True)
+        for idx, (x, label) in enumerate(dataset):
+            t0 = time.perf_counter()
+            if mode == "certify":
+                pred, radius = smooth.certify(x, sm_cfg["n0"], sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"])
+            else:
+                pred, radius = smooth.predict(x, sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"]), 0.0
+            dt = time.perf_counter() - t0
+            rec = dict(idx=idx, label=int(label), predict=int(pred), radius=float(radius), correct=int(pred == label), time=dt)
+            self.records.append(rec)
+            if f:
+                if mode == "certify":
+                    print(f"{idx}\t{label}\t{pred}\t{radius:.6f}\t{rec['correct']}\t{dt:.3f}", file=f, flush=True)
+                else:
+                    print(f"{idx}\t{label}\t{pred}\t{rec['correct']}\t{dt:.3f}", file=f, flush=True)
+        if f:
+            f.close()
+        return self.records
+
+    def summary(self, radii=(0.0, 0.25, 0.5, 1.0)):
+        n = max(len(self.records), 1)
+        out = {"images": len(self.records),
+               "abstain_rate": sum(r["predict"] == Smooth.ABSTAIN for r in self.records) / n,
+               "accuracy": sum(r["correct"] for r in self.records) / n,
+               "images_per_s": len(self.records) / max(sum(r["time"] for r in self.records), 1e-9)}
+        for r0 in radii:   # certified accuracy at radius r: correct and certified radius >= r (README.md:52-59)
+            out[f"certified_acc@{r0}"] = sum(r["correct"] and r["radius"] >= r0 for r in self.records) / n
+        return out
+
+
+def build_classifier(model_cfg, num_classes, max_batch, device_index):
+    from ..classifier import HipClassifier
+    clf = HipClassifier(mode=model_cfg.get("mode", "vit_head"), num_classes=num_classes, max_batch=max_batch,
+                        device=device_index, **model_cfg.get("dims", {}))
+    path = model_cfg.get("weights")
+    if path:
+        state = torch.load(path, map_location="cpu", weights_only=True)
+        clf.load_state_dict(state.get("model_state_dict", state), strict=False)
+    else:
+        clf.init_synthetic(seed=int(model_cfg.get("seed", 0)))
+    return clf
+
+
+@registry.register_agent("image_text_certify")
+class MiniGPT4CertifyAgent(BaseAgent, CertifyLoop):
+    mode = "certify"
+
+    def __init__(self, dataset=None, classifier=None):
+        super().__init__()
+        self.dataset = dataset
+        self.classifier = classifier
+        self.result = None
+
+    def run(self):
+        cfg = self.config
+        sm = dict(cfg["run"]["smoothing"])
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        clf = self.classifier or build_classifier(cfg.get("model", {}), sm["num_classes"], sm["batch_size"], local)
+        self._model = clf
+        self._device = getattr(clf, "device", None)
+        smooth = Smooth(clf, sm["num_classes"], sm["sigma"], seed=int(cfg["run"].get("seed", 0)))
+        data = self.dataset
+        if data is None:
+            d = cfg.get("data", {})
+            img = getattr(clf, "chw", (3, 224, 224))[1]
+            data = synthetic_dataset(int(d.get("num_images", 10)), img, int(d.get("seed", 1234)), self._device, sm["num_classes"])
+        out_dir = cfg["run"].get("output_dir")
+        log = None
+        if out_dir and int(os.environ.get("RANK", "0")) == 0:
+            os.makedirs(out_dir, exist_ok=True)
+            log = os.path.join(out_dir, f"{self.mode}.tsv")
+        self.certify_dataset(sm, data, smooth, log, mode=self.mode)
+        self.result = self.summary(tuple(sm.get("radii", (0.0, 0.25, 0.5, 1.0))))
+        if log:
+            with open(os.path.join(out_dir, f"{self.mode}_summary.json"), "w") as f:
+                json.dump(self.result, f)
+
+    def finalize(self):
+        return self.result
