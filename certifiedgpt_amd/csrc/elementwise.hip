@@ -20,8 +20,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ------------------------------------------------------------------------------------------ LayerNorm
 // One wave per row; the row lives in registers (NCH float2 per lane) between the mean, the centred variance
 // and the normalise pass, so x is read from HBM exactly once.  Requires D even and D <= NCH*128.
+// With `delta` (fp16) the kernel first applies the pending residual update x += delta and writes x back: the
+// reference's `x = x + attn(...)` / `x = x + mlp(...)` (eva_vit.py:180-181), where under autocast the branch output is
+// an fp16 tensor added to the fp32 stream -- done here instead of as a read-modify-write in the GEMM epilogue.
 template <int NCH>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int64_t ldx,
+                                                        const half_t* __restrict__ delta, int64_t ldd,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         half_t* __restrict__ y16, int64_t ldy16,
@@ -29,13 +33,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + row * ldx;
+    float* xr = x + row * ldx;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     float2 v[NCH];
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = c * 128 + lane * 2;
         v[c] = (col < D) ? *reinterpret_cast<const float2*>(xr + col) : make_float2(0.f, 0.f);
+        if (delta && col < D) {
+            const f16x2 d = *reinterpret_cast<const f16x2*>(delta + row * ldd + col);
+            v[c].x += (float)d[0];
+            v[c].y += (float)d[1];
+            *reinterpret_cast<float2*>(xr + col) = v[c];
+        }
         s += v[c].x + v[c].y;
     }
     const float mean = wave_sum(s) / (float)D;
@@ -58,12 +69,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const float a = (v[c].x - mean) * rstd * gm.x + bt.x;
             const float b = (v[c].y - mean) * rstd * gm.y + bt.y;
             if (y16) {
-                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
                 *reinterpret_cast<f16x2*>(y16 + row * ldy16 + col) = f16x2{(half_t)a, (half_t)b};
             }
             if (y32) *reinterpret_cast<float2*>(y32 + row * ldy32 + col) = make_float2(a, b);
         }
     }
+}
+
+// x[row, :] += delta[row, :]  (the last block's pending residual update, when no LayerNorm follows on those rows)
+__global__ __launch_bounds__(256) void add_delta_kernel(float* __restrict__ x, int64_t ldx, const half_t* __restrict__ delta,
+                                                        int64_t ldd, int64_t rows, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one float2 per thread
+    const int half_d = D >> 1;
+    if (i >= rows * half_d) return;
+    const int64_t r = i / half_d;
+    const int col = (int)(i - r * half_d) * 2;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    float2 v = *reinterpret_cast<const float2*>(x + r * ldx + col);
+    const f16x2 d = *reinterpret_cast<const f16x2*>(delta + r * ldd + col);
+    v.x += (float)d[0];
+    v.y += (float)d[1];
+    *reinterpret_cast<float2*>(x + r * ldx + col) = v;
 }
 
 // ------------------------------------------------------------------ noise (+ im2col of the patch embedding)
@@ -218,13 +244,21 @@ inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + pe
 
 }  // namespace
 
-hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
-                            half_t* y16, int64_t ldy16, float* y32, int64_t ldy32, int64_t rows, int D,
+hipError_t launch_add_delta(float* x, int64_t ldx, const half_t* delta, int64_t ldd, int64_t rows, int D,
                             hipStream_t stream) {
     if (rows <= 0) return hipSuccess;
-    if (D <= 0 || (D & 1) || D > 32 * 128 || (ldx & 1) || (ldy16 & 1) || (ldy32 & 1)) return hipErrorInvalidValue;
+    if ((D & 1) || (ldx & 1) || (ldd & 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_delta_kernel, dim3(blocks_for(rows * (D >> 1))), dim3(256), 0, stream, x, ldx, delta, ldd, rows, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(float* x, int64_t ldx, const half_t* delta, int64_t ldd, const float* gamma,
+                            const float* beta, float eps, half_t* y16, int64_t ldy16, float* y32, int64_t ldy32,
+                            int64_t rows, int D, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    if (D <= 0 || (D & 1) || D > 32 * 128 || (ldx & 1) || (ldy16 & 1) || (ldy32 & 1) || (ldd & 1)) return hipErrorInvalidValue;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define CGPT_LN(NCH) hipLaunchKernelGGL(layernorm_kernel<NCH>, grid, block, 0, stream, x, ldx, gamma, beta, eps, \
+#define CGPT_LN(NCH) hipLaunchKernelGGL(layernorm_kernel<NCH>, grid, block, 0, stream, x, ldx, delta, ldd, gamma, beta, eps, \
                                         y16, ldy16, y32, ldy32, rows, D)
     if (D <= 2 * 128) CGPT_LN(2);
     else if (D <= 6 * 128) CGPT_LN(6);

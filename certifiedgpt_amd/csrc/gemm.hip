@@ -31,19 +31,18 @@ constexpr int GROUP_M = 8;
 
 // Exact-erf GELU (nn.GELU default, eva_vit.py:50,61) = x * Phi(x), with erf from Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7, far below the fp16 rounding of the output): Phi(|x|) = 1 - 0.5 * P(t) * exp(-x^2/2),
-// t = 1/(1 + 0.3275911 |x|/sqrt2).  ~17 VALU ops instead of ocml erff's ~40: the fc1 epilogue runs 128 of these per lane.
+// t = 1/(1 + 0.3275911 |x|/sqrt2).  13 VALU ops (2 transcendental) instead of ocml erff's ~40: the fc1 epilogue runs 128
+// of these per lane and is NOT hidden behind MFMAs at one workgroup per CU.
 __device__ __forceinline__ float gelu_erf(float x) {
     const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);       // exp(-x^2/2)
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
-    float pl = fmaf(t, 1.061405429f, -1.453152027f);
-    pl = fmaf(t, pl, 1.421413741f);
-    pl = fmaf(t, pl, -0.284496736f);
-    pl = fmaf(t, pl, 0.254829592f);
-    const float h = 0.5f * pl * t * e;                                               // 0.5 * erfc(|x|/sqrt2)
-    const float phi = x >= 0.0f ? 1.0f - h : h;
-    return x * phi;
+    float pl = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);                   // 0.5 * A&S 7.1.26 polynomial
+    pl = fmaf(t, pl, 0.5f * 1.421413741f);
+    pl = fmaf(t, pl, 0.5f * -0.284496736f);
+    pl = fmaf(t, pl, 0.5f * 0.254829592f);
+    const float h = pl * t * e;                                                      // 0.5 * erfc(|x|/sqrt2) = 1 - Phi(|x|)
+    return fmaf(-fabsf(x), h, fmaxf(x, 0.0f));                                       // x>=0: x - x h ; x<0: x h
 }
-
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float v) {
     if constexpr (EPI == EPI_F16) {
@@ -67,6 +66,20 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int& tm, int& tn) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = t / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_grp = t - grp * per_group;
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+}
+
+// Same map for a VIRTUAL block id t in [0, nwg) (persistent kernel: physical block b walks t = b, b + grid, ...; with a grid
+// that is a multiple of 8, t and b sit on the same XCD).
+__device__ __forceinline__ void tile_of_virtual_block(int vb, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int per_group = GROUP_M * tiles_n;
     const int grp = t / per_group;
@@ -211,23 +224,26 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
 
     const int tiles_m = (p.M + BM2 - 1) / BM2;
     const int tiles_n = (p.N + BN_ - 1) / BN_;
-    int tm, tn;
-    tile_of_block(tiles_m, tiles_n, tm, tn);
+    const int ntiles = tiles_m * tiles_n;
 
     // ---- staging sources: piece i of this wave covers tile rows wave*(rows/8) + i*8 .. +7
     const int lr = lane >> 3, cpos = lane & 7;
     const half_t* a_src[A_INSTR];
     const half_t* b_src[B_INSTR];
+    int tm = 0, tn = 0;
+    auto set_tile = [&](int t) {
+        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn);
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        const int r = wave * (BM2 / 8) + i * 8 + lr;
-        a_src[i] = p.A + (int64_t)(tm * BM2 + r) * p.lda + ((cpos ^ ((r >> 1) & 7)) << 3);
-    }
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int r = wave * (BM2 / 8) + i * 8 + lr;
+            a_src[i] = p.A + (int64_t)(tm * BM2 + r) * p.lda + ((cpos ^ ((r >> 1) & 7)) << 3);
+        }
 #pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        const int r = wave * (BN_ / 8) + i * 8 + lr;
-        b_src[i] = p.W + (int64_t)(tn * BN_ + r) * p.ldw + ((cpos ^ ((r >> 1) & 7)) << 3);
-    }
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int r = wave * (BN_ / 8) + i * 8 + lr;
+            b_src[i] = p.W + (int64_t)(tn * BN_ + r) * p.ldw + ((cpos ^ ((r >> 1) & 7)) << 3);
+        }
+    };
     auto stage_load = [&](int stage, int kt) {
         half_t* sa = smem2 + stage * STAGE + wave * (BM2 / 8) * BK;
         half_t* sb = smem2 + stage * STAGE + A_ELEMS + wave * (BN_ / 8) * BK;
@@ -246,52 +262,144 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
     const int a_rd = (wr * (BM2 / WM) + r15) * BK;
     const int b_rd = A_ELEMS + (wc * (BN_ / WN) + r15) * BK;
 
+    // acc[i][j] holds the TRANSPOSED 16x16 tile (operands swapped: W fragment first), so that
+    // acc[i][j][r] = C[m = i*16 + (lane&15)][n = j*16 + 4*(lane>>4) + r]: a lane owns 4 CONSECUTIVE columns of one row
+    // and the epilogue issues 8/16-byte vector stores instead of four 2/4-byte ones.
     f32x4 acc[TM][TN];
+    constexpr int HM = TM / 2;   // the wave tile is walked in two M-halves so that fragment reads run one group ahead
+    f16x8 a0[HM], a1[HM], b0[TN], b1[TN];
+#define CGPT_LDA(dst, st_, ko_, h_)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                          \
+        dst[i] = *reinterpret_cast<const f16x8*>((st_) + a_rd + ((h_) * HM + i) * 16 * BK + (ko_));
+#define CGPT_LDB(dst, st_, ko_)                                                                             \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
+        dst[j] = *reinterpret_cast<const f16x8*>((st_) + b_rd + j * 16 * BK + (ko_));
+#define CGPT_MM_ROWS(af_, bf_, h_, i0_, i1_)                                                                \
+    _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i)                                                   \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                      \
+            acc[(h_) * HM + i][j] =                                                                         \
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(bf_[j], af_[i], acc[(h_) * HM + i][j], 0, 0, 0);
+#define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
+
+    // Schedule of one K-tile (4 groups of HM*TN MFMAs).  Each group starts with one row of MFMAs, THEN issues the
+    // fragment reads of the next group, then runs its remaining MFMAs: the compiler-inserted lgkmcnt wait in front of a
+    // group is therefore exact (no younger read outstanding) and the reads get >= (HM-1)*TN MFMAs of cover.
+    // Persistent: this workgroup walks tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...  `c` counts K-tiles across the
+    // whole walk; K-tile c lives in LDS stage c & 1, so the first K-tile of the NEXT output tile can be requested before
+    // this tile's epilogue (its stage was last read two K-tiles ago) and lands while the epilogue stores drain.
+    const int nk = p.K / BK;
+    int c = 0;
+    int t = blockIdx.x;
+    if (t < ntiles) { set_tile(t); stage_load(0, 0); }
+    for (; t < ntiles; t += gridDim.x) {
+    f32x4 bias4[TN];                                    // this lane's 4 x TN bias values; loaded now, used in the epilogue
+    {
+        const int nb0 = tn * BN_ + wc * (BN_ / WN) + 4 * g;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && nb0 + j * 16 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + j * 16);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    stage_load(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage_load((kt + 1) & 1, kt + 1);
-        const half_t* st = smem2 + (kt & 1) * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ko = ks ? k_off1 : k_off0;
-            f16x8 af[TM], bf[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + ko);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK + ko);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+    CGPT_LDA(a0, smem2 + (c & 1) * STAGE, k_off0, 0)
+    CGPT_LDB(b0, smem2 + (c & 1) * STAGE, k_off0)
+    for (int kt = 0; kt < nk; ++kt, ++c) {
+        const half_t* st = smem2 + (c & 1) * STAGE;
+        const half_t* nx = smem2 + ((c + 1) & 1) * STAGE;
+        const bool more = kt + 1 < nk;
+        // K-tile kt+1 -> the other stage: every wave finished reading it before the barrier that ended iteration kt-1
+        if (more && !(p.ablate & 1)) stage_load((c + 1) & 1, kt + 1);
+        CGPT_FENCE
+        CGPT_MM_ROWS(a0, b0, 0, 0, 1)            // G1: k-step 0, M-half 0
+        CGPT_FENCE
+        CGPT_LDA(a1, st, k_off0, 1)
+        CGPT_FENCE
+        CGPT_MM_ROWS(a0, b0, 0, 1, HM)
+        CGPT_FENCE
+        CGPT_MM_ROWS(a1, b0, 1, 0, 1)            // G2: k-step 0, M-half 1
+        CGPT_FENCE
+        CGPT_LDA(a0, st, k_off1, 0)
+        CGPT_LDB(b1, st, k_off1)
+        CGPT_FENCE
+        CGPT_MM_ROWS(a1, b0, 1, 1, HM)
+        CGPT_FENCE
+        CGPT_MM_ROWS(a0, b1, 0, 0, 1)            // G3: k-step 1, M-half 0
+        CGPT_FENCE
+        CGPT_LDA(a1, st, k_off1, 1)
+        CGPT_FENCE
+        CGPT_MM_ROWS(a0, b1, 0, 1, HM)
+        CGPT_FENCE
+        // every read of `st` by this wave has been issued; vmcnt(0) + lgkmcnt(0) + s_barrier: K-tile kt+1 has landed for
+        // every wave and nobody still reads `st`.  G4 runs AFTER the barrier, covering the next tile's first reads.
         __syncthreads();
+        if (more) {
+            CGPT_LDA(a0, nx, k_off0, 0)
+            CGPT_LDB(b0, nx, k_off0)
+        }
+        CGPT_FENCE
+        CGPT_MM_ROWS(a1, b1, 1, 0, HM)           // G4: k-step 1, M-half 1
+        CGPT_FENCE
     }
-
-    const int m_base = tm * BM2 + wr * (BM2 / WM) + 4 * g;
-    const int n_base = tn * BN_ + wc * (BN_ / WN) + r15;
+    // ---- epilogue of tile (etm, etn).  Order matters for the in-order vmcnt counter: (1) pin the bias registers (their
+    // loads were issued at tile start and retired by the K-loop barriers), (2) request K-tile 0 of the NEXT tile, (3) compute
+    // and store.  On the full-tile fast path the stores then stream back to back with no s_waitcnt between them; a load in
+    // this phase would make every later use wait for the previous store to complete.
+    const int etm = tm, etn = tn;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n_base + j * 16;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.0f;
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
+    if (t + (int)gridDim.x < ntiles) { set_tile(t + gridDim.x); stage_load(c & 1, 0); }
+
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int m0 = etm * BM2 + wr * (BM2 / WM) + r15;      // lane owns rows m0 + i*16, columns n0 + j*16 .. +3
+    const int n0 = etn * BN_ + wc * (BN_ / WN) + 4 * g;
+    const bool full = (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2);
+    auto emit = [&](int i, int j, int m, int n) {
+        f32x4 v = acc[i][j] + bias4[j];
+        int64_t orow = (int64_t)m * p.ldo;
+        if constexpr (EPI == EPI_PATCH) {
+            const int b = m / p.patches, pp = m - b * p.patches;
+            orow = ((int64_t)b * (p.patches + 1) + 1 + pp) * p.ldo;
+            v += *reinterpret_cast<const f32x4*>(p.aux + (int64_t)(1 + pp) * p.ldaux + n);
+        }
+        if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n);
+        if constexpr (EPI == EPI_F16 || EPI == EPI_F16_GELU) {
+            if constexpr (EPI == EPI_F16_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<f16x4*>(reinterpret_cast<half_t*>(p.out) + orow + n) = hv;
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow + n) = v;
+        }
+    };
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) emit(i, j, m0 + i * 16, n0 + j * 16);
+    } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int m = m0 + i * 16;
+            if (m >= p.M) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_base + i * 16 + r;
-                if (m >= p.M) continue;
-                epilogue_store<EPI>(p, m, n, acc[i][j][r] + bias);
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + j * 16;
+                if (n >= p.N) continue;
+                if ((p.ablate & 2) && acc[i][j][0] != 123.456f) continue;
+                emit(i, j, m, n);
             }
         }
     }
+    }   // persistent tile loop
+#undef CGPT_MM_ROWS
+#undef CGPT_FENCE
 }
 
 template <int EPI, int BN_>
@@ -305,7 +413,15 @@ hipError_t launch_v2(const GemmParams& p, hipStream_t stream) {
         configured = true;
     }
     const int tiles = ((p.M + 255) / 256) * ((p.N + BN_ - 1) / BN_);
-    hipLaunchKernelGGL((gemm2_f16_kernel<EPI, BN_>), dim3(tiles), dim3(512), lds_bytes, stream, p);
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = tiles < num_cus ? tiles : num_cus;     // one 512-thread workgroup per CU (LDS-limited), persistent
+    hipLaunchKernelGGL((gemm2_f16_kernel<EPI, BN_>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
@@ -324,13 +440,17 @@ hipError_t launch_v2_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
 }  // namespace
 
 int g_gemm_kernel = 0;
+int g_gemm_ablate = 0;
 
-hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream) {
+hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.ablate = g_gemm_ablate;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
         return hipErrorInvalidValue;
     // Kernel choice (speed only).  v2 needs A readable for round_up(M,256) rows and W for round_up(N,BN) rows: the
     // library's buffers are padded to 256 rows; weights to 128 rows, so BN=256 only when N % 256 == 0.
-    const int force = g_gemm_kernel;   // 0 auto, 1 v1 (128x128), 2 v2 BN=256, 3 v2 BN=128  (cgpt_set_option)
+    const bool vec_ok = (p.N % 4) == 0 && (p.ldo % 4) == 0 && (p.ldaux % 4) == 0;
+    const int force = vec_ok ? g_gemm_kernel : 1;   // 0 auto, 1 v1 (128x128), 2 v2 BN=256, 3 v2 BN=128  (cgpt_set_option)
     if (force == 2 && (p.N % 256) == 0) return launch_v2_epi<256>(epilogue, p, stream);
     if (force == 3 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
     if (force == 0 && p.M >= 1024) {

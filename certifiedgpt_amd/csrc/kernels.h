@@ -26,8 +26,10 @@ struct GemmParams {
     const float* aux; int64_t ldaux;
     int M, N, K;
     int patches;                  // EPI_PATCH: P (patches per image)
+    int ablate = 0;               // measurement only: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
+extern int g_gemm_ablate;
 extern int g_gemm_kernel;   // kernel override for A/B measurements: 0 auto, 1 v1, 2 v2<256>, 3 v2<128>
 
 // ---------------------------------------------------------------------------------------- attention
@@ -46,8 +48,12 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 // --------------------------------------------------------------------------------------- LayerNorm
 // y = (x - mean) / sqrt(var + eps) * gamma + beta over D, fp32 statistics (base_model.py:281-287).
 // Input row r is x + r*ldx; outputs y16 (fp16, may be null) and y32 (fp32, may be null).
-hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
-                            half_t* y16, int64_t ldy16, float* y32, int64_t ldy32, int64_t rows, int D,
+// delta (fp16, may be null): pending residual update, applied first and written back: x += delta (eva_vit.py:180-181).
+hipError_t launch_layernorm(float* x, int64_t ldx, const half_t* delta, int64_t ldd, const float* gamma,
+                            const float* beta, float eps, half_t* y16, int64_t ldy16, float* y32, int64_t ldy32,
+                            int64_t rows, int D, hipStream_t stream);
+// x += delta without a LayerNorm (after the last block).
+hipError_t launch_add_delta(float* x, int64_t ldx, const half_t* delta, int64_t ldd, int64_t rows, int D,
                             hipStream_t stream);
 
 // ------------------------------------------------------------------------------ noise / im2col / misc

@@ -82,7 +82,7 @@ struct cgpt_model {
     std::vector<VitLayer> vit;
     std::vector<QfLayer> qf;
     // workspace
-    half_t *Apatch, *xn, *qkv, *attn, *hid, *cls16, *emb, *kv_all, *qh16, *qqkv, *qctx, *qq, *qff, *pooled;
+    half_t *Apatch, *xn, *qkv, *attn, *hid, *delta, *cls16, *emb, *kv_all, *qh16, *qqkv, *qctx, *qq, *qff, *pooled;
     float *resid, *logits, *qemb0, *qh32, *qtmp, *llama;
     int last_nb = 0;
     bool profile = false;
@@ -262,6 +262,7 @@ cgpt_status build(cgpt_model* m) {
     CGCHK(new_act16(m, M, 3 * D, &m->qkv));
     CGCHK(new_act16(m, M, D, &m->attn));
     CGCHK(new_act16(m, M, m->mlp, &m->hid));
+    CGCHK(new_act16(m, M, D, &m->delta));
     CGCHK(new_act16(m, nb, D, &m->cls16));
     CGCHK(new_act32(m, nb, m->K, &m->logits));
     if (full) {
@@ -327,31 +328,35 @@ cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_s
                m->Kpatch_p, 0, st));
     HIPCHK(launch_cls_rows(m->cls, m->pos, m->resid, D, T, nb, D, st));
     const int hd = D / c.vit_heads;
+    // Residual adds (x = x + attn(..), x = x + mlp(..), eva_vit.py:180-181) are deferred: proj / fc2 write their fp16
+    // output to `delta` (the reference's autocast Linear output is fp16 too) and the NEXT LayerNorm kernel applies
+    // resid += delta while it reads the row anyway; no GEMM epilogue reads the fp32 stream.
     for (int i = 0; i < c.vit_depth; ++i) {                                   // Block.forward, eva_vit.py:178-185
         const VitLayer& L = m->vit[i];
-        HIPCHK(launch_layernorm(m->resid, D, L.n1w, L.n1b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st));
+        HIPCHK(launch_layernorm(m->resid, D, i ? m->delta : nullptr, Dk, L.n1w, L.n1b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st));
         CGCHK(gemm(m, EPI_F16, m->xn, Dk, L.Wqkv, Dk, L.bqkv, m->qkv, m->ld_qkv, nullptr, 0, M, 3 * D, Dk, 0, st));
         CGCHK(attention(m->qkv, m->ld_qkv, (int64_t)T * m->ld_qkv, m->qkv + D, m->ld_qkv, m->qkv + 2 * D, m->ld_qkv,
                         (int64_t)T * m->ld_qkv, m->attn, Dk, (int64_t)T * Dk, nb, c.vit_heads, hd, T, T, st));
-        CGCHK(gemm(m, EPI_RESID, m->attn, Dk, L.Wproj, Dk, L.bproj, m->resid, D, m->resid, D, M, D, Dk, 0, st));
-        HIPCHK(launch_layernorm(m->resid, D, L.n2w, L.n2b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st));
+        CGCHK(gemm(m, EPI_F16, m->attn, Dk, L.Wproj, Dk, L.bproj, m->delta, Dk, nullptr, 0, M, D, Dk, 0, st));
+        HIPCHK(launch_layernorm(m->resid, D, m->delta, Dk, L.n2w, L.n2b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st));
         CGCHK(gemm(m, EPI_F16_GELU, m->xn, Dk, L.Wfc1, Dk, L.bfc1, m->hid, m->mlp_k, nullptr, 0, M, m->mlp, Dk, 1, st));
-        CGCHK(gemm(m, EPI_RESID, m->hid, m->mlp_k, L.Wfc2, m->mlp_k, L.bfc2, m->resid, D, m->resid, D, M, D, m->mlp_k, 0, st));
+        CGCHK(gemm(m, EPI_F16, m->hid, m->mlp_k, L.Wfc2, m->mlp_k, L.bfc2, m->delta, Dk, nullptr, 0, M, D, m->mlp_k, 0, st));
     }
     if (c.mode == CGPT_MODE_VIT_HEAD) {
-        // ln_vision on the CLS rows only (row stride T*D), then the build-side head
-        HIPCHK(launch_layernorm(m->resid, (int64_t)T * D, m->lnvw, m->lnvb, c.ln_vision_eps, m->cls16, Dk, nullptr, 0, nb, D, st));
+        // last block's pending update, then ln_vision on the CLS rows only (row stride T*D) and the build-side head
+        HIPCHK(launch_add_delta(m->resid, D, m->delta, Dk, M, D, st));
+        HIPCHK(launch_layernorm(m->resid, (int64_t)T * D, nullptr, 0, m->lnvw, m->lnvb, c.ln_vision_eps, m->cls16, Dk, nullptr, 0, nb, D, st));
         CGCHK(gemm(m, EPI_F32, m->cls16, Dk, m->Whead, Dk, m->bhead, m->logits, m->K, nullptr, 0, nb, m->K, Dk, 0, st));
         m->last_nb = nb;
         return CGPT_OK;
     }
     // ---- MiniGPT4.encode_img tail: ln_vision -> Q-Former -> llama_proj (minigpt4.py:129-141)
     const int H = m->H, Hk = m->Hk, Q = m->Q, MQ = nb * Q, qhd = H / c.qf_heads;
-    HIPCHK(launch_layernorm(m->resid, D, m->lnvw, m->lnvb, c.ln_vision_eps, m->emb, Dk, nullptr, 0, M, D, st));
+    HIPCHK(launch_layernorm(m->resid, D, m->delta, Dk, m->lnvw, m->lnvb, c.ln_vision_eps, m->emb, Dk, nullptr, 0, M, D, st));
     // K/V of every cross-attention layer in one GEMM over the image tokens (Qformer.py:185-188,203-204)
     CGCHK(gemm(m, EPI_F16, m->emb, Dk, m->Wkv_all, Dk, m->bkv_all, m->kv_all, m->ld_kv, nullptr, 0, M, (int)m->ld_kv, Dk, 0, st));
     // embeddings: LayerNorm(query_tokens) (Qformer.py:104-106), expanded over the batch (minigpt4.py:132)
-    HIPCHK(launch_layernorm(m->qtok, H, m->qembw, m->qembb, c.qf_ln_eps, nullptr, 0, m->qemb0, H, Q, H, st));
+    HIPCHK(launch_layernorm(m->qtok, H, nullptr, 0, m->qembw, m->qembb, c.qf_ln_eps, nullptr, 0, m->qemb0, H, Q, H, st));
     HIPCHK(launch_broadcast_rows(m->qemb0, Q, H, nb, m->qh32, H, m->qh16, Hk, st));
     for (int i = 0; i < c.qf_layers; ++i) {                                   // BertLayer.forward, Qformer.py:402-474
         const QfLayer& L = m->qf[i];
@@ -359,19 +364,19 @@ cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_s
         CGCHK(attention(m->qqkv, 3 * H, (int64_t)Q * 3 * H, m->qqkv + H, 3 * H, m->qqkv + 2 * H, 3 * H, (int64_t)Q * 3 * H,
                         m->qctx, Hk, (int64_t)Q * Hk, nb, c.qf_heads, qhd, Q, Q, st));
         CGCHK(gemm(m, EPI_RESID, m->qctx, Hk, L.Wo, Hk, L.bo, m->qtmp, H, m->qh32, H, MQ, H, Hk, 0, st));   // Qformer.py:285-288
-        HIPCHK(launch_layernorm(m->qtmp, H, L.lnw, L.lnb, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
+        HIPCHK(launch_layernorm(m->qtmp, H, nullptr, 0, L.lnw, L.lnb, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
         if (L.xattn_index >= 0) {                                            // Qformer.py:432-447
             const half_t* Kx = m->kv_all + (int64_t)L.xattn_index * 2 * H;
             CGCHK(gemm(m, EPI_F16, m->qh16, Hk, L.Wxq, Hk, L.bxq, m->qq, Hk, nullptr, 0, MQ, H, Hk, 0, st));
             CGCHK(attention(m->qq, Hk, (int64_t)Q * Hk, Kx, m->ld_kv, Kx + H, m->ld_kv, (int64_t)T * m->ld_kv, m->qctx, Hk,
                             (int64_t)Q * Hk, nb, c.qf_heads, qhd, Q, T, st));
             CGCHK(gemm(m, EPI_RESID, m->qctx, Hk, L.Wxo, Hk, L.bxo, m->qtmp, H, m->qh32, H, MQ, H, Hk, 0, st));
-            HIPCHK(launch_layernorm(m->qtmp, H, L.xlnw, L.xlnb, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
+            HIPCHK(launch_layernorm(m->qtmp, H, nullptr, 0, L.xlnw, L.xlnb, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
         }
         // feed_forward_chunk_query, Qformer.py:481-484
         CGCHK(gemm(m, EPI_F16_GELU, m->qh16, Hk, L.Wi, Hk, L.bi, m->qff, m->Fk, nullptr, 0, MQ, m->F, Hk, 0, st));
         CGCHK(gemm(m, EPI_RESID, m->qff, m->Fk, L.Wo2, m->Fk, L.bo2, m->qtmp, H, m->qh32, H, MQ, H, m->Fk, 0, st));
-        HIPCHK(launch_layernorm(m->qtmp, H, L.ln2w, L.ln2b, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
+        HIPCHK(launch_layernorm(m->qtmp, H, nullptr, 0, L.ln2w, L.ln2b, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
     }
     CGCHK(gemm(m, EPI_F32, m->qh16, Hk, m->Wproj_l, Hk, m->bproj_l, m->llama, m->PD, nullptr, 0, MQ, m->PD, Hk, 0, st));
     // build-side label head on the mean of the query tokens
@@ -600,6 +605,7 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
         g_gemm_kernel = value;
         return CGPT_OK;
     }
+    if (k == "gemm_ablate") { g_gemm_ablate = value; return CGPT_OK; }   // measurement only (wrong results)
     return cgpt_fail(CGPT_ERR_NOT_FOUND, "cgpt_set_option: unknown option '" + k + "'");
 }
 
@@ -640,6 +646,19 @@ cgpt_status cgpt_gemm_f16(const void* A_dev, int64_t lda, const void* W_dev, int
     return CGPT_OK;
 }
 
+cgpt_status cgpt_linear_f16(const void* A_dev, int64_t lda, const void* W_dev, int64_t ldw, const float* bias_dev,
+                            void* out_dev, int64_t ldo, const float* aux_dev, int64_t ldaux, int64_t M, int64_t N, int64_t K,
+                            int32_t epilogue, void* stream) {
+    if (!A_dev || !W_dev || !out_dev || M < 1 || N < 1 || K < 64 || (K % 64) || (lda % 8) || (ldw % 8) || epilogue < 0 ||
+        epilogue > 3 || (epilogue == 3 && !aux_dev))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_linear_f16: bad argument");
+    GemmParams p;
+    p.A = (const half_t*)A_dev; p.lda = lda; p.W = (const half_t*)W_dev; p.ldw = ldw; p.bias = bias_dev;
+    p.out = out_dev; p.ldo = ldo; p.aux = aux_dev; p.ldaux = ldaux; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.patches = 1;
+    HIPCHK(launch_gemm(epilogue, p, (hipStream_t)stream));
+    return CGPT_OK;
+}
+
 cgpt_status cgpt_attention_f16(const void* Q_dev, int64_t ldq, const void* K_dev, const void* V_dev, int64_t ldkv,
                                void* O_dev, int64_t ldo, int32_t B, int32_t heads, int32_t head_dim, int32_t Tq, int32_t Tk,
                                float scale, void* stream) {
@@ -658,7 +677,7 @@ cgpt_status cgpt_attention_f16(const void* Q_dev, int64_t ldq, const void* K_dev
 cgpt_status cgpt_layernorm(const float* x_dev, int64_t ldx, const float* gamma_dev, const float* beta_dev, float eps,
                            void* y_dev, int64_t ldy, float* y32_dev, int64_t ldy32, int64_t rows, int32_t D, void* stream) {
     if (!x_dev || !gamma_dev || !beta_dev || (!y_dev && !y32_dev)) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_layernorm: null argument");
-    hipError_t e = launch_layernorm(x_dev, ldx, gamma_dev, beta_dev, eps, (half_t*)y_dev, ldy, y32_dev, ldy32, rows, D,
+    hipError_t e = launch_layernorm(const_cast<float*>(x_dev), ldx, nullptr, 0, gamma_dev, beta_dev, eps, (half_t*)y_dev, ldy, y32_dev, ldy32, rows, D,
                                     (hipStream_t)stream);
     if (e != hipSuccess) return cgpt_fail(e == hipErrorInvalidValue ? CGPT_ERR_INVALID : CGPT_ERR_HIP,
                                           std::string("cgpt_layernorm: ") + hipGetErrorString(e));

@@ -169,6 +169,11 @@ cgpt_status cgpt_set_option(const char* key, int32_t value);
  * library's own buffers always are); K%64==0.  out is fp32 [M,ldc]. */
 cgpt_status cgpt_gemm_f16(const void* A_dev, int64_t lda, const void* W_dev, int64_t ldw, const float* bias_dev,
                           float* C_dev, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+/* nn.Linear with a fused epilogue: 0 = fp16 out (acc + bias), 1 = fp16 out gelu_erf(acc + bias), 2 = fp32 out,
+ * 3 = fp32 out = aux + acc + bias (aux may alias out: the residual add x = x + f(x), eva_vit.py:180-181). */
+cgpt_status cgpt_linear_f16(const void* A_dev, int64_t lda, const void* W_dev, int64_t ldw, const float* bias_dev,
+                            void* out_dev, int64_t ldo, const float* aux_dev, int64_t ldaux, int64_t M, int64_t N, int64_t K,
+                            int32_t epilogue, void* stream);
 /* softmax(scale * Q K^T) V per (batch, head): Q [B,Tq,ldq] K,V [B,Tk,ldkv] fp16 with head h at column h*head_dim;
  * O [B,Tq,ldo] fp16.  head_dim in {64, 88}.  (eva_vit.py:133-150; Qformer.py:244-264 with zero masks) */
 cgpt_status cgpt_attention_f16(const void* Q_dev, int64_t ldq, const void* K_dev, const void* V_dev, int64_t ldkv,
