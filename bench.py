@@ -5,7 +5,8 @@ One "step" = one `Smooth.certify(x, n0=100, n=100, alpha=0.001, batch_size)` of 
 sigma = 0.5 through EVA-ViT-G (random-init weights of that architecture) + ln_vision(CLS) + Linear(1408->1000) head
 (BASELINE.json configs[1]); i.e. n0 + n = 200 classifier forwards (reference smoothing.py:44,48).
 With N GPUs the Monte-Carlo samples of every `_sample_noise` are sharded over the ranks and the int64 vote histograms are
-summed with one RCCL all-reduce (strong scaling: the work per certified image is fixed).
+summed with one RCCL all-reduce (strong scaling: the work per certified image is fixed).  The n0 selection draws and the n
+estimation draws are independent, so `certify` runs them in the same classifier batches (batch_size = (n0+n)/N per GPU).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -97,7 +98,8 @@ def main():
 
     import certifiedgpt_amd as cg
     dev = torch.device("cuda", local)
-    per_gpu = -(-max(N0, N) // world)                                  # largest shard of a _sample_noise call
+    # certify runs its n0 + n draws as ONE fused pass; the largest per-rank share of it is one batch
+    per_gpu = -(-N0 // world) + -(-N // world)
     clf = cg.HipClassifier(mode="vit_head", num_classes=NUM_CLASSES, max_batch=per_gpu, device=local)
     clf.init_synthetic(seed=0)                                         # identical weights on every rank
     smooth = cg.Smooth(clf, NUM_CLASSES, SIGMA, seed=42)
@@ -144,7 +146,7 @@ def main():
                                    "image, Smooth.certify n0=100 n=100 alpha=0.001 sigma=0.5 (BASELINE configs[1])",
                        "n0": N0, "n": N, "alpha": ALPHA, "sigma": SIGMA, "num_classes": NUM_CLASSES,
                        "batch_size_per_gpu": per_gpu, "forwards_per_image": N0 + N,
-                       "parallelism": f"sample-sharded x{world}, one int64[{NUM_CLASSES}] all-reduce per _sample_noise"},
+                       "parallelism": f"sample-sharded x{world}, one int64[2,{NUM_CLASSES}] all-reduce per certify"},
             "forwards_per_s": value * (N0 + N),
             "vit_tflops_end_to_end": value * (N0 + N) * F_VIT / 1e12,
             "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel<EPI_F16_GELU> (ViT MLP fc1, M=batch*257, N=6144, K=1408)",

@@ -131,6 +131,19 @@ class HipClassifier:
                                                   C.c_void_p(counts.data_ptr()), _stream_ptr()))
         return counts
 
+    def sample_counts_pair(self, x, first_a, num_a, first_b, num_b, batch_size, sigma, seed):
+        """Selection + estimation draws of one `certify` in a single device pass (cgpt_sample_counts2).
+        Returns an int64 device tensor [2, num_classes]: row 0 = votes of samples [first_a, first_a+num_a),
+        row 1 = votes of [first_b, first_b+num_b).  Identical to two sample_counts calls."""
+        x = self._check_x(x, False)
+        counts = torch.zeros((2, self.num_classes), dtype=torch.int64, device=x.device)
+        if num_a + num_b > 0:
+            _lib.check(self._L.cgpt_sample_counts2(self._h, C.c_void_p(x.data_ptr()), first_a, num_a,
+                                                   C.c_void_p(counts[0].data_ptr()), first_b, num_b,
+                                                   C.c_void_p(counts[1].data_ptr()), min(batch_size, self.max_batch), sigma,
+                                                   seed, _stream_ptr()))
+        return counts
+
     def forward_logits(self, x, first_sample, num, sigma, seed):
         x = self._check_x(x, False)
         out = torch.empty((num, self.num_classes), dtype=torch.float32, device=x.device)

@@ -95,10 +95,12 @@ __global__ __launch_bounds__(256) void add_delta_kernel(float* __restrict__ x, i
 // ------------------------------------------------------------------ noise (+ im2col of the patch embedding)
 // Destination of pixel (c, y, x) in the im2col matrix: row = b*P + (y/ps)*(img/ps) + x/ps,
 // column = c*ps*ps + (y%ps)*ps + x%ps   (= the flattening of Conv2d weight [D,3,ps,ps], eva_vit.py:202).
+// Sample index of batch row b: first_sample + b for b < na, else first_b + (b - na) (two index ranges in one batch:
+// the selection and estimation draws of Smooth.certify, smoothing.py:44,48).
 template <bool NOISE>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ src, int img, int ps,
-                                                     int64_t first_sample, int nb, float sigma, uint64_t seed,
-                                                     half_t* __restrict__ A, int64_t lda) {
+                                                     int64_t first_sample, int na, int64_t first_b, int nb, float sigma,
+                                                     uint64_t seed, half_t* __restrict__ A, int64_t lda) {
     const int groups = 3 * img * img / 4;                       // 4 consecutive pixels of one image row
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (int64_t)groups * nb) return;
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ s
     // NOISE: src is the single clean image x[3,img,img]; else src is the batch [nb,3,img,img]
     float4 px = *reinterpret_cast<const float4*>(src + (NOISE ? 0 : (int64_t)b * 3 * img * img) + e);
     if (NOISE) {
-        const float4 z = normal4(seed, (uint64_t)(first_sample + b), (uint32_t)grp, 0u);
+        const int64_t sample = b < na ? first_sample + b : first_b + (b - na);
+        const float4 z = normal4(seed, (uint64_t)sample, (uint32_t)grp, 0u);
         // explicit fma: the fused path and cgpt_noise_batch must round identically (bit-identical votes)
         px.x = __fmaf_rn(sigma, z.x, px.x); px.y = __fmaf_rn(sigma, z.y, px.y);
         px.z = __fmaf_rn(sigma, z.z, px.z); px.w = __fmaf_rn(sigma, z.w, px.w);
@@ -183,7 +186,8 @@ __global__ void mean_rows_kernel(const float* __restrict__ src, int64_t lds, int
 // then a 6-step xor-shuffle butterfly keeps (larger value, then smaller index): ndarray/tensor argmax semantics
 // "first maximal index" (smoothing.py:97).  Lane 0 adds the vote with one 64-bit atomic (smoothing.py:98,101-105).
 __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ logits, int64_t ld, int64_t num, int K,
-                                                   unsigned long long* __restrict__ counts) {
+                                                   unsigned long long* __restrict__ counts, int64_t na,
+                                                   unsigned long long* __restrict__ counts_b) {
     const int lane = threadIdx.x & 63;
     const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= num) return;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ log
         const int oi = __shfl_xor(bi, o);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if (lane == 0) atomicAdd(counts + bi, 1ull);
+    if (lane == 0) atomicAdd((s < na ? counts : counts_b) + bi, 1ull);   // rows >= na belong to the second range
 }
 
 // ------------------------------------------------------------------------------------- fills and casts
@@ -269,13 +273,13 @@ hipError_t launch_layernorm(float* x, int64_t ldx, const half_t* delta, int64_t 
     return hipGetLastError();
 }
 
-hipError_t launch_noise_im2col(const float* x, int img, int ps, int64_t first_sample, int nb, float sigma,
-                               uint64_t seed, half_t* A, int64_t lda, hipStream_t stream) {
+hipError_t launch_noise_im2col(const float* x, int img, int ps, int64_t first_sample, int na, int64_t first_b, int nb,
+                               float sigma, uint64_t seed, half_t* A, int64_t lda, hipStream_t stream) {
     if (nb <= 0) return hipSuccess;
     if ((img & 3) || (img % ps)) return hipErrorInvalidValue;
     const int64_t n = (int64_t)nb * 3 * img * img / 4;
-    hipLaunchKernelGGL(im2col_kernel<true>, dim3(blocks_for(n)), dim3(256), 0, stream, x, img, ps, first_sample, nb,
-                       sigma, seed, A, lda);
+    hipLaunchKernelGGL(im2col_kernel<true>, dim3(blocks_for(n)), dim3(256), 0, stream, x, img, ps, first_sample, na,
+                       first_b, nb, sigma, seed, A, lda);
     return hipGetLastError();
 }
 
@@ -284,7 +288,7 @@ hipError_t launch_im2col(const float* images, int img, int ps, int nb, half_t* A
     if ((img & 3) || (img % ps)) return hipErrorInvalidValue;
     const int64_t n = (int64_t)nb * 3 * img * img / 4;
     hipLaunchKernelGGL(im2col_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, stream, images, img, ps, (int64_t)0, nb,
-                       0.0f, (uint64_t)0, A, lda);
+                       (int64_t)0, nb, 0.0f, (uint64_t)0, A, lda);
     return hipGetLastError();
 }
 
@@ -318,10 +322,11 @@ hipError_t launch_mean_rows(const float* src, int64_t lds, int rows, int D, int 
     return hipGetLastError();
 }
 
-hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int64_t* counts, hipStream_t stream) {
+hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int64_t* counts, int64_t na, int64_t* counts_b,
+                       hipStream_t stream) {
     if (num <= 0) return hipSuccess;
     hipLaunchKernelGGL(vote_kernel, dim3((unsigned)((num + 3) / 4)), dim3(256), 0, stream, logits, ld, num, K,
-                       reinterpret_cast<unsigned long long*>(counts));
+                       reinterpret_cast<unsigned long long*>(counts), na, reinterpret_cast<unsigned long long*>(counts_b));
     return hipGetLastError();
 }
 

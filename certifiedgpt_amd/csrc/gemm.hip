@@ -447,17 +447,16 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     p.ablate = g_gemm_ablate;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
         return hipErrorInvalidValue;
-    // Kernel choice (speed only).  v2 needs A readable for round_up(M,256) rows and W for round_up(N,BN) rows: the
-    // library's buffers are padded to 256 rows; weights to 128 rows, so BN=256 only when N % 256 == 0.
+    // Kernel choice (speed only).  v2 needs A readable for round_up(M,256) rows and W for round_up(N,256) rows: the
+    // library's activation and weight buffers are padded to 256 rows.
     const bool vec_ok = (p.N % 4) == 0 && (p.ldo % 4) == 0 && (p.ldaux % 4) == 0;
     const int force = vec_ok ? g_gemm_kernel : 1;   // 0 auto, 1 v1 (128x128), 2 v2 BN=256, 3 v2 BN=128  (cgpt_set_option)
-    if (force == 2 && (p.N % 256) == 0) return launch_v2_epi<256>(epilogue, p, stream);
+    if (force == 2) return launch_v2_epi<256>(epilogue, p, stream);   // W must be readable for round_up(N,256) rows
     if (force == 3 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
     if (force == 0 && p.M >= 1024) {
-        // measured on MI355X at M = 25700 / 3341 (profiles/r01/gemm_ab_*.txt): 256x256 wins whenever it tiles N exactly;
-        // 256x128 wins for N % 256 != 0 except the long-K, large-M fc2 shape where two 4-wave blocks per CU hide more.
-        if ((p.N % 256) == 0) return launch_v2_epi<256>(epilogue, p, stream);
-        if ((p.N % 128) == 0 && !(p.K > 2048 && p.M >= 8192)) return launch_v2_epi<128>(epilogue, p, stream);
+        // measured on MI355X (profiles/r01/gemm_ab_*.txt): the 256x256 direct-to-LDS kernel wins on every ViT / Q-Former
+        // shape at M >= 3341, also when N is not a multiple of 256 (N padded: weights are allocated with 256-row padding).
+        return launch_v2_epi<256>(epilogue, p, stream);
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

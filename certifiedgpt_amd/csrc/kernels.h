@@ -10,7 +10,7 @@ typedef _Float16 half_t;
 // ---------------------------------------------------------------------------------------------- GEMM
 // C = A[M,K] * W[N,K]^T with a fused epilogue.  A/W are fp16, K contiguous.  Requirements (the library's
 // own buffers satisfy them): K % 64 == 0; A readable for round_up(M,256) rows; W readable for
-// round_up(N,128) rows; pad K-columns of A and W hold zeros.
+// round_up(N,256) rows; pad K-columns of A and W hold zeros.
 enum GemmEpilogue {
     EPI_F16 = 0,        // out_f16[m,n] = acc + bias[n]
     EPI_F16_GELU = 1,   // out_f16[m,n] = gelu_erf(acc + bias[n])                        (eva_vit.py:60-61)
@@ -59,8 +59,9 @@ hipError_t launch_add_delta(float* x, int64_t ldx, const half_t* delta, int64_t 
 // ------------------------------------------------------------------------------ noise / im2col / misc
 // smoothing.py:95-96 fused with the patch-embed im2col (eva_vit.py:202,209): for sample s = first_sample + b,
 // patch p, element e=(c,i,j):  A[(b*P + p), e] = fp16(x[c, py*ps+i, px*ps+j] + sigma * eps_s[c, .., ..]).
-hipError_t launch_noise_im2col(const float* x, int img, int ps, int64_t first_sample, int nb, float sigma,
-                               uint64_t seed, half_t* A, int64_t lda, hipStream_t stream);
+// Batch row b carries sample first_sample + b for b < na and first_b + (b - na) otherwise (two index ranges per batch).
+hipError_t launch_noise_im2col(const float* x, int img, int ps, int64_t first_sample, int na, int64_t first_b, int nb,
+                               float sigma, uint64_t seed, half_t* A, int64_t lda, hipStream_t stream);
 // Same im2col for caller-supplied images [nb,3,img,img] (no noise).
 hipError_t launch_im2col(const float* images, int img, int ps, int nb, half_t* A, int64_t lda, hipStream_t stream);
 // out[b, :] = x + sigma * eps_{first_sample + b}   (fp32 images; handle-free C-ABI cgpt_noise_batch)
@@ -76,7 +77,9 @@ hipError_t launch_broadcast_rows(const float* src, int rows, int D, int nb, floa
 hipError_t launch_mean_rows(const float* src, int64_t lds, int rows, int D, int nb, half_t* dst16, int64_t ld16,
                             hipStream_t stream);
 // smoothing.py:97-98,101-105: counts[argmax_k logits[b,k]] += 1 (first maximal index), one wave per sample.
-hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int64_t* counts, hipStream_t stream);
+// Rows b < na vote into counts, rows b >= na into counts_b.
+hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int64_t* counts, int64_t na, int64_t* counts_b,
+                       hipStream_t stream);
 // Fill a tensor from the counter-based normal stream: dst = mean + std * z (fp16 or fp32 destination, 2-D with ld).
 hipError_t launch_fill_normal(void* dst, int is_f16, int64_t rows, int64_t cols, int64_t ld, float mean, float std,
                               uint64_t seed, uint64_t tensor_id, hipStream_t stream);

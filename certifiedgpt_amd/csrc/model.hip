@@ -3,7 +3,7 @@
 // is MiniGPT-4's image encoder, minigpt4.py:121-149).
 //
 // HBM layout (one handle = one GPU; everything stays resident, nothing is re-allocated per call):
-//   weights    fp16 matrices [round_up(N,128)][round_up(K,64)] zero padded (nn.Linear layout, K contiguous);
+//   weights    fp16 matrices [round_up(N,256)][round_up(K,64)] zero padded (nn.Linear layout, K contiguous);
 //              fp32 vectors for biases / LayerNorm affine / cls_token / pos_embed / query_tokens.
 //   workspace  sized for max_batch samples: im2col A [nb*P][640] fp16, residual stream [nb*T][D] fp32,
 //              LayerNorm output / attention output [nb*T][D] fp16, qkv [nb*T][3D] fp16, MLP hidden [nb*T][6144] fp16, ...
@@ -109,10 +109,10 @@ void add_view(cgpt_model* m, const std::string& name, void* base, bool f16, int6
     m->views.push_back(v);
 }
 
-// fp16 GEMM weight [N,K] (zero padded to [ru(N,128)][ru(K,64)])
+// fp16 GEMM weight [N,K] (zero padded to [ru(N,256)][ru(K,64)])
 cgpt_status new_mat(cgpt_model* m, int64_t N, int64_t Kd, half_t** out) {
     void* p;
-    CGCHK(dev_alloc(m, (size_t)ru(N, 128) * ru(Kd, 64) * sizeof(half_t), &p));
+    CGCHK(dev_alloc(m, (size_t)ru(N, 256) * ru(Kd, 64) * sizeof(half_t), &p));
     *out = (half_t*)p;
     return CGPT_OK;
 }
@@ -316,12 +316,13 @@ cgpt_status attention(const half_t* Q, int64_t ldq, int64_t qbs, const half_t* K
 }
 
 // One base-classifier forward for nb samples.  src: the clean image (noise=true) or nb images (noise=false).
-cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_sample, int nb, float sigma, uint64_t seed,
-                    hipStream_t st) {
+// With noise: batch row b is sample first_sample + b for b < na, first_b + (b - na) otherwise.
+cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_sample, int na, int64_t first_b, int nb,
+                    float sigma, uint64_t seed, hipStream_t st) {
     const cgpt_config& c = m->cfg;
     const int D = m->D, Dk = m->Dk, T = m->T, P = m->P, M = nb * T;
     // K1 + im2col: smoothing.py:95-96 fused into the patch-embed operand (eva_vit.py:202,209)
-    if (noise) HIPCHK(launch_noise_im2col(src, c.img_size, c.patch_size, first_sample, nb, sigma, seed, m->Apatch, m->Kpatch_p, st));
+    if (noise) HIPCHK(launch_noise_im2col(src, c.img_size, c.patch_size, first_sample, na, first_b, nb, sigma, seed, m->Apatch, m->Kpatch_p, st));
     else HIPCHK(launch_im2col(src, c.img_size, c.patch_size, nb, m->Apatch, m->Kpatch_p, st));
     // patch-embed GEMM + bias + pos_embed, scattered to token rows 1..P; CLS row = cls + pos[0]  (eva_vit.py:333-340)
     CGCHK(gemm(m, EPI_PATCH, m->Apatch, m->Kpatch_p, m->Wpatch, m->Kpatch_p, m->bpatch, m->resid, D, m->pos, D, nb * P, D,
@@ -530,8 +531,31 @@ cgpt_status cgpt_sample_counts(cgpt_handle h, const float* x_dev, int64_t first_
     int64_t done = 0;
     while (done < num) {                                   // smoothing.py:91-98
         const int nb = (int)((num - done < batch_size) ? (num - done) : batch_size);
-        CGCHK(forward(h, x_dev, true, first_sample + done, nb, sigma, noise_seed, st));
-        HIPCHK(launch_vote(h->logits, h->K, nb, h->K, counts_dev, st));
+        CGCHK(forward(h, x_dev, true, first_sample + done, nb, 0, nb, sigma, noise_seed, st));
+        HIPCHK(launch_vote(h->logits, h->K, nb, h->K, counts_dev, nb, counts_dev, st));
+        done += nb;
+    }
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_sample_counts2(cgpt_handle h, const float* x_dev, int64_t first_a, int64_t num_a, int64_t* counts_a_dev,
+                                int64_t first_b, int64_t num_b, int64_t* counts_b_dev, int64_t batch_size, float sigma,
+                                uint64_t noise_seed, void* stream) {
+    CGCHK(check_call(h, x_dev, counts_a_dev, num_a, "cgpt_sample_counts2"));
+    if (!counts_b_dev || num_b < 0) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_sample_counts2: bad second range");
+    if (batch_size < 1 || batch_size > h->cfg.max_batch)
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_sample_counts2: batch_size must be in [1, max_batch]");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int64_t total = num_a + num_b;
+    int64_t done = 0;                                      // position in the concatenation of the two ranges
+    while (done < total) {
+        const int nb = (int)((total - done < batch_size) ? (total - done) : batch_size);
+        const int na = (int)(done >= num_a ? 0 : ((num_a - done < nb) ? (num_a - done) : nb));   // rows of range A in this batch
+        const int64_t fa = first_a + done;                                                     // used only when na > 0
+        const int64_t fb = first_b + (done > num_a ? done - num_a : 0);
+        CGCHK(forward(h, x_dev, true, fa, na, fb, nb, sigma, noise_seed, st));
+        HIPCHK(launch_vote(h->logits, h->K, nb, h->K, counts_a_dev, na, counts_b_dev, st));
         done += nb;
     }
     return CGPT_OK;
@@ -543,7 +567,7 @@ cgpt_status cgpt_forward_logits(cgpt_handle h, const float* x_dev, int64_t first
     if (num < 1 || num > h->cfg.max_batch) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_forward_logits: num must be in [1, max_batch]");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
-    CGCHK(forward(h, x_dev, true, first_sample, (int)num, sigma, noise_seed, st));
+    CGCHK(forward(h, x_dev, true, first_sample, (int)num, 0, (int)num, sigma, noise_seed, st));
     HIPCHK(hipMemcpyAsync(logits_dev, h->logits, (size_t)num * h->K * sizeof(float), hipMemcpyDeviceToDevice, st));
     return CGPT_OK;
 }
@@ -553,7 +577,7 @@ cgpt_status cgpt_classify(cgpt_handle h, const float* images_dev, int64_t num, f
     if (num < 1 || num > h->cfg.max_batch) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_classify: num must be in [1, max_batch]");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
-    CGCHK(forward(h, images_dev, false, 0, (int)num, 0.f, 0, st));
+    CGCHK(forward(h, images_dev, false, 0, (int)num, 0, (int)num, 0.f, 0, st));
     HIPCHK(hipMemcpyAsync(logits_dev, h->logits, (size_t)num * h->K * sizeof(float), hipMemcpyDeviceToDevice, st));
     return CGPT_OK;
 }
@@ -593,7 +617,7 @@ cgpt_status cgpt_noise_batch(const float* x_dev, int64_t chw, int64_t first_samp
 
 cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes, int64_t* counts_dev, void* stream) {
     if (!logits_dev || !counts_dev || num < 0 || num_classes < 1) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_vote: bad argument");
-    HIPCHK(launch_vote(logits_dev, num_classes, num, num_classes, counts_dev, (hipStream_t)stream));
+    HIPCHK(launch_vote(logits_dev, num_classes, num, num_classes, counts_dev, num, counts_dev, (hipStream_t)stream));
     return CGPT_OK;
 }
 

@@ -60,9 +60,29 @@ class Smooth(object):
     def certify(self, x: torch.tensor, n0: int, n: int, alpha: float, batch_size: int) -> (int, float):
         """smoothing.py:29-56.  Returns (predicted class, certified L2 radius) or (ABSTAIN, 0.0)."""
         self.base_classifier.eval()
-        counts_selection = self._sample_noise(x, n0, batch_size)
-        counts_estimation = self._sample_noise(x, n, batch_size)
+        if hasattr(self.base_classifier, "sample_counts_pair"):
+            # the n0 selection draws and the n estimation draws are independent (smoothing.py:44,48): run them in the same
+            # classifier batches and sum both histograms with ONE all-reduce.  Same sample indices as the two-call path.
+            counts_selection, counts_estimation = self._sample_noise_pair(x, n0, n, batch_size)
+        else:
+            counts_selection = self._sample_noise(x, n0, batch_size)
+            counts_estimation = self._sample_noise(x, n, batch_size)
         return self.certify_from_counts(counts_selection, counts_estimation, n, alpha)
+
+    def _sample_noise_pair(self, x, n0: int, n: int, batch_size):
+        first = self._next_sample
+        self._next_sample += n0 + n
+        rank, world = _world(self.process_group)
+        lo_a, hi_a = shard_range(n0, rank, world)
+        lo_b, hi_b = shard_range(n, rank, world)
+        with torch.no_grad():
+            counts = self.base_classifier.sample_counts_pair(x, first + lo_a, hi_a - lo_a, first + n0 + lo_b, hi_b - lo_b,
+                                                             batch_size, float(self.sigma), self.seed)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
+        c = counts.cpu().numpy().astype(int)
+        return c[0], c[1]
 
     def predict(self, x: torch.tensor, n: int, alpha: float, batch_size: int) -> int:
         """smoothing.py:58-79.  Returns the predicted class or ABSTAIN."""

@@ -118,6 +118,13 @@ cgpt_status cgpt_init_synthetic_weights(cgpt_handle h, uint64_t seed, void* stre
 cgpt_status cgpt_sample_counts(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num,
                                int64_t batch_size, float sigma, uint64_t noise_seed,
                                int64_t* counts_dev, void* stream);
+/* Two sample-index ranges in ONE pass: Smooth.certify draws n0 selection samples and n estimation samples
+ * (smoothing.py:44,48); they are independent, so both can ride in the same classifier batches.  Samples
+ * [first_a, first_a+num_a) vote into counts_a_dev, samples [first_b, first_b+num_b) into counts_b_dev; batches of up to
+ * batch_size samples may span the two ranges.  Results are identical to two cgpt_sample_counts calls. */
+cgpt_status cgpt_sample_counts2(cgpt_handle h, const float* x_dev, int64_t first_a, int64_t num_a, int64_t* counts_a_dev,
+                                int64_t first_b, int64_t num_b, int64_t* counts_b_dev, int64_t batch_size, float sigma,
+                                uint64_t noise_seed, void* stream);
 /* Same batches, but return the logits [num, num_classes] float32 instead of voting (parity tests; num <= max_batch). */
 cgpt_status cgpt_forward_logits(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num,
                                 float sigma, uint64_t noise_seed, float* logits_dev, void* stream);
@@ -165,7 +172,7 @@ cgpt_status cgpt_set_option(const char* key, int32_t value);
 
 /* ---- raw kernels exported for unit tests and reuse (all fp16 operands are IEEE binary16) ----
  * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) ; A row stride lda, W row stride ldw (elements), fp32 accumulate.
- * Requirements: A must be readable for ceil(M/256)*256 rows and W for ceil(N/128)*128 rows (zero padded; the
+ * Requirements: A must be readable for ceil(M/256)*256 rows and W for ceil(N/256)*256 rows (zero padded; the
  * library's own buffers always are); K%64==0.  out is fp32 [M,ldc]. */
 cgpt_status cgpt_gemm_f16(const void* A_dev, int64_t lda, const void* W_dev, int64_t ldw, const float* bias_dev,
                           float* C_dev, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);

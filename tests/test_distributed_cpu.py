@@ -34,17 +34,26 @@ class IndexedEngine:
         return torch.from_numpy(np.bincount(labels.astype(np.int64), minlength=K).astype(np.int64))
 
 
+class PairEngine(IndexedEngine):
+    """Adds the fused selection+estimation protocol (HipClassifier.sample_counts_pair)."""
+
+    def sample_counts_pair(self, x, first_a, num_a, first_b, num_b, batch_size, sigma, seed):
+        a = IndexedEngine.sample_counts(self, x, first_a, num_a, batch_size, sigma, seed)
+        b = IndexedEngine.sample_counts(self, x, first_b, num_b, batch_size, sigma, seed)
+        return torch.stack([a, b])
+
+
 def _single():
     s = cg.Smooth(IndexedEngine(), K, 0.5, seed=11)
     x = torch.zeros(3, 8, 8)
     return s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, fused=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        eng = IndexedEngine()
+        eng = PairEngine() if fused else IndexedEngine()
         s = cg.Smooth(eng, K, 0.5, seed=11)
         x = torch.zeros(3, 8, 8)
         out = (s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist())
@@ -79,3 +88,25 @@ def test_two_rank_gloo_matches_single_process():
     assert got[1][2][:2] == [(50, 50, 32), (150, 50, 32)]
     # predict: 125 samples -> 63 + 62, starting at cursor 200
     assert got[0][2][2] == (200, 63, 32) and got[1][2][2] == (263, 62, 32)
+
+
+def test_fused_certify_pass_matches_two_pass_single_and_two_ranks():
+    """certify through sample_counts_pair (one pass, one all-reduce for both histograms) == the two-call path."""
+    expect = _single()
+    s = cg.Smooth(PairEngine(), K, 0.5, seed=11)
+    x = torch.zeros(3, 8, 8)
+    assert (s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist()) == expect
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, calls in got:
+        assert out == expect, (rank, out, expect)
+    # rank 1: selection shard [50,100), estimation shard [150,200) -- same indices as the unfused path
+    assert got[1][2][:2] == [(50, 50, 32), (150, 50, 32)]

@@ -115,6 +115,18 @@ def test_smooth_matches_oracle_on_identical_noise(mode):
     assert p == cg.Smooth.ABSTAIN or 0 <= p < K
 
 
+def test_fused_pair_pass_is_bit_identical_to_two_passes():
+    K = 10
+    clf, p16, params, cfg = tiny_pair(mo.MODE_ENCODE_IMG, num_classes=K, max_batch=16)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    for (fa, na, fb, nb, bs) in [(0, 24, 24, 40, 16), (5, 7, 100, 9, 16), (0, 0, 3, 5, 4), (3, 5, 0, 0, 4), (0, 16, 16, 16, 16)]:
+        pair = clf.sample_counts_pair(x0, fa, na, fb, nb, bs, 0.25, 5)
+        a = clf.sample_counts(x0, fa, na, bs, 0.25, 5)
+        b = clf.sample_counts(x0, fb, nb, bs, 0.25, 5)
+        assert torch.equal(pair[0], a) and torch.equal(pair[1], b), (fa, na, fb, nb, bs)
+        assert int(pair[0].sum()) == na and int(pair[1].sum()) == nb
+
+
 def test_generic_module_path_uses_hip_noise_and_vote():
     """A base classifier that is an ordinary callable on PyTorch-ROCm (e.g. MiniGPT-4 + Vicuna): noise and vote are HIP."""
     K = 5
@@ -173,6 +185,8 @@ def test_vitg_counts_invariant_to_batching_and_sharding(vitg):
     assert torch.equal(full, parts)
     other = clf.sample_counts(x, 100, 100, 100, 0.5, 42)                  # fresh indices: a different draw
     assert int(other.sum()) == 100
+    pair = clf.sample_counts_pair(x, 0, 100, 100, 100, 100, 0.5, 42)      # certify's fused pass, batches span the ranges
+    assert torch.equal(pair[0], full) and torch.equal(pair[1], other)
     logits = clf.forward_logits(x, 0, 100, 0.5, 42)
     assert torch.isfinite(logits).all()
     assert torch.equal(torch.bincount(logits.argmax(1), minlength=1000), full)
