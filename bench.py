@@ -97,6 +97,9 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     import certifiedgpt_amd as cg
+    if os.environ.get("CGPT_GEMM_KERNEL"):          # A/B measurements only; default = the library's own choice
+        from certifiedgpt_amd import _lib
+        _lib.check(cg.lib().cgpt_set_option(b"gemm_kernel", int(os.environ["CGPT_GEMM_KERNEL"])))
     dev = torch.device("cuda", local)
     # certify runs its n0 + n draws as ONE fused pass; the largest per-rank share of it is one batch
     per_gpu = -(-N0 // world) + -(-N // world)

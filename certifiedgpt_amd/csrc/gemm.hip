@@ -197,6 +197,56 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
     }
 }
 
+
+// Epilogue shared by the 256-row kernels: the lane owns rows m0 + i*16 and columns n0 + j*16 .. +3 (transposed
+// accumulator tiles), so every (i, j) is one 8- or 16-byte store.  `full` = the tile lies completely inside C: then there
+// are no guards and no loads, and the stores issue back to back (a load here would make every later use wait for the
+// previous STORE: vmcnt retires in order).
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_256(const GemmParams& p, f32x4 (&acc)[TM][TN], f32x4 (&bias4)[TN], int m0, int n0,
+                                                  bool full) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    auto emit = [&](int i, int j, int m, int n) {
+        f32x4 v = acc[i][j] + bias4[j];
+        int64_t orow = (int64_t)m * p.ldo;
+        if constexpr (EPI == EPI_PATCH) {
+            const int b = m / p.patches, pp = m - b * p.patches;
+            orow = ((int64_t)b * (p.patches + 1) + 1 + pp) * p.ldo;
+            v += *reinterpret_cast<const f32x4*>(p.aux + (int64_t)(1 + pp) * p.ldaux + n);
+        }
+        if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n);
+        if constexpr (EPI == EPI_F16 || EPI == EPI_F16_GELU) {
+            if constexpr (EPI == EPI_F16_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<f16x4*>(reinterpret_cast<half_t*>(p.out) + orow + n) = hv;
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow + n) = v;
+        }
+    };
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) emit(i, j, m0 + i * 16, n0 + j * 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + i * 16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + j * 16;
+                if (n >= p.N) continue;
+                if ((p.ablate & 2) && acc[i][j][0] != 123.456f) continue;
+                emit(i, j, m, n);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ v2
 // 256 x BN x 64 tile, 8 waves, operands staged straight into LDS by global_load_lds_dwordx4 (no VGPR round
 // trip, no ds_write: the register-staged v1 kernel is bound by the ~79 B/clk ds_write_b128 path).
@@ -274,11 +324,18 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
 #define CGPT_LDB(dst, st_, ko_)                                                                             \
     _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
         dst[j] = *reinterpret_cast<const f16x8*>((st_) + b_rd + j * 16 * BK + (ko_));
+#ifdef CGPT_SETPRIO
+#define CGPT_PRIO(x) __builtin_amdgcn_s_setprio(x);
+#else
+#define CGPT_PRIO(x)
+#endif
 #define CGPT_MM_ROWS(af_, bf_, h_, i0_, i1_)                                                                \
+    CGPT_PRIO(1)                                                                                            \
     _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i)                                                   \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                      \
             acc[(h_) * HM + i][j] =                                                                         \
-                __builtin_amdgcn_mfma_f32_16x16x32_f16(bf_[j], af_[i], acc[(h_) * HM + i][j], 0, 0, 0);
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(bf_[j], af_[i], acc[(h_) * HM + i][j], 0, 0, 0);      \
+    CGPT_PRIO(0)
 #define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
 
     // Schedule of one K-tile (4 groups of HM*TN MFMAs).  Each group starts with one row of MFMAs, THEN issues the
@@ -290,6 +347,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
     const int nk = p.K / BK;
     int c = 0;
     int t = blockIdx.x;
+#ifdef CGPT_STAMPS
+    unsigned long long stamp_vm = 0, stamp_bar = 0, stamp_epi = 0, stamp_ld = 0;
+    const unsigned long long stamp_begin = __builtin_amdgcn_s_memtime();
+#endif
     if (t < ntiles) { set_tile(t); stage_load(0, 0); }
     for (; t < ntiles; t += gridDim.x) {
     f32x4 bias4[TN];                                    // this lane's 4 x TN bias values; loaded now, used in the epilogue
@@ -313,7 +374,20 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
         const half_t* nx = smem2 + ((c + 1) & 1) * STAGE;
         const bool more = kt + 1 < nk;
         // K-tile kt+1 -> the other stage: every wave finished reading it before the barrier that ended iteration kt-1
-        if (more && !(p.ablate & 1)) stage_load((c + 1) & 1, kt + 1);
+#ifndef CGPT_STAGGER
+#define CGPT_STAGGER 0
+#endif
+        // LDS-DMA issue is expensive (60-185 cycles per 1-KiB piece, MI355X guide): the two waves of a SIMD (w, w+4)
+        // issue their 8 pieces at different points of the K-tile so that one of them always feeds the matrix pipe.
+#ifdef CGPT_STAMPS
+        const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        if (more && !(p.ablate & 1) && (CGPT_STAGGER == 0 || wave < 4)) stage_load((c + 1) & 1, kt + 1);
+#ifdef CGPT_STAMPS
+        stamp_ld += __builtin_amdgcn_s_memtime() - tl0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         CGPT_FENCE
         CGPT_MM_ROWS(a0, b0, 0, 0, 1)            // G1: k-step 0, M-half 0
         CGPT_FENCE
@@ -321,12 +395,16 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
         CGPT_FENCE
         CGPT_MM_ROWS(a0, b0, 0, 1, HM)
         CGPT_FENCE
+        if (CGPT_STAGGER == 1 && more && !(p.ablate & 1) && wave >= 4) stage_load((c + 1) & 1, kt + 1);
+        CGPT_FENCE
         CGPT_MM_ROWS(a1, b0, 1, 0, 1)            // G2: k-step 0, M-half 1
         CGPT_FENCE
         CGPT_LDA(a0, st, k_off1, 0)
         CGPT_LDB(b1, st, k_off1)
         CGPT_FENCE
         CGPT_MM_ROWS(a1, b0, 1, 1, HM)
+        CGPT_FENCE
+        if (CGPT_STAGGER == 2 && more && !(p.ablate & 1) && wave >= 4) stage_load((c + 1) & 1, kt + 1);
         CGPT_FENCE
         CGPT_MM_ROWS(a0, b1, 0, 0, 1)            // G3: k-step 1, M-half 0
         CGPT_FENCE
@@ -336,7 +414,19 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
         CGPT_FENCE
         // every read of `st` by this wave has been issued; vmcnt(0) + lgkmcnt(0) + s_barrier: K-tile kt+1 has landed for
         // every wave and nobody still reads `st`.  G4 runs AFTER the barrier, covering the next tile's first reads.
+#ifdef CGPT_STAMPS
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp_vm += ts1 - ts0; stamp_bar += ts2 - ts1;
+#else
+        __syncthreads();
+#endif
         if (more) {
             CGPT_LDA(a0, nx, k_off0, 0)
             CGPT_LDB(b0, nx, k_off0)
@@ -350,6 +440,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
     // and store.  On the full-tile fast path the stores then stream back to back with no s_waitcnt between them; a load in
     // this phase would make every later use wait for the previous store to complete.
     const int etm = tm, etn = tn;
+#ifdef CGPT_STAMPS
+    const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
     if (t + (int)gridDim.x < ntiles) { set_tile(t + gridDim.x); stage_load(c & 1, 0); }
@@ -397,7 +490,16 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
             }
         }
     }
+#ifdef CGPT_STAMPS
+    stamp_epi += __builtin_amdgcn_s_memtime() - te0;
+#endif
     }   // persistent tile loop
+#ifdef CGPT_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+        d[0] = __builtin_amdgcn_s_memtime() - stamp_begin; d[1] = stamp_ld; d[2] = stamp_bar; d[3] = stamp_epi;
+    }
+#endif
 #undef CGPT_MM_ROWS
 #undef CGPT_FENCE
 }
@@ -437,14 +539,378 @@ hipError_t launch_v2_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ v3
+// Same tile, staging and swizzle as v2<256>, different time structure (the "phase" structure of the MI355X guide):
+// measured on v2 (in-kernel s_memtime stamps, profiles/r01/gemm_v2_stamps.txt) the OLDER wave of every SIMD wins MFMA
+// arbitration, finishes its K-tile early and parks 25 % of its time at the barrier, after which the younger wave runs
+// alone with its 8 LDS-DMA issues (40-70 cycles each) and 24 fragment reads exposed.  Here the two waves of a SIMD
+// (w and w+4 = the top / bottom 128 rows of the tile) execute the same program ONE SLOT apart:
+//     slot:      0     1     2     3     4     5     6     7   | 8 ...
+//     waves 0-3  L0    M0    L1    M1    L2    M2    L3    M3  | L0'          L = fragment reads (+ LDS-DMA issue, L0/L1)
+//     waves 4-7  (M3)  L0    M0    L1    M1    L2    M2    L3  | M3           M = 16 MFMAs (one quadrant of the wave tile)
+// with an s_barrier between slots, so in every slot one wave of each SIMD feeds the matrix pipe while its partner
+// does everything else.  Quadrant order (k-step, M-half) = (0,0) (0,1) (1,1) (1,0): B fragments are re-read only twice.
+// Hazards: every L segment ends with lgkmcnt(0) BEFORE its barrier, so a stage is never overwritten while a read of it
+// is outstanding (K-tile t+1 goes to the other stage, requested in L0/L1 of K-tile t); every wave retires its own
+// LDS-DMA (vmcnt(0)) in the segment that occupies slot 7, so after that slot's barrier K-tile t+1 is visible to all.
+// NQ = phases per K-tile: 4 (16-MFMA quadrants) or 2 (32 MFMAs = one k-step of the whole wave tile per phase).
+template <int EPI, int NQ>
+__global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
+    constexpr int BM2 = 256, BN_ = 256, WN = 4, WM = 2;
+    constexpr int TM = 8, TN = 4, HM = 4;
+    constexpr int A_ELEMS = BM2 * BK, B_ELEMS = BN_ * BK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int A_INSTR = 4, B_INSTR = 4;
+    extern __shared__ __attribute__((aligned(16))) half_t smem3[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const bool late = wave >= 4;                       // the half that runs one slot behind
+    const int r15 = lane & 15, g = lane >> 4;
+
+    const int tiles_m = (p.M + BM2 - 1) / BM2;
+    const int tiles_n = (p.N + BN_ - 1) / BN_;
+    const int ntiles = tiles_m * tiles_n;
+
+    const int lr = lane >> 3, cpos = lane & 7;
+    const half_t* a_src[A_INSTR];
+    const half_t* b_src[B_INSTR];
+    int tm = 0, tn = 0;
+    auto set_tile = [&](int t) {
+        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn);
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int r = wave * (BM2 / 8) + i * 8 + lr;
+            a_src[i] = p.A + (int64_t)(tm * BM2 + r) * p.lda + ((cpos ^ ((r >> 1) & 7)) << 3);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int r = wave * (BN_ / 8) + i * 8 + lr;
+            b_src[i] = p.W + (int64_t)(tn * BN_ + r) * p.ldw + ((cpos ^ ((r >> 1) & 7)) << 3);
+        }
+    };
+    auto load_a = [&](int stage, int kt) {
+        half_t* sa = smem3 + stage * STAGE + wave * (BM2 / 8) * BK;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 8 * BK), 16, 0, 0);
+    };
+    auto load_b = [&](int stage, int kt) {
+        half_t* sb = smem3 + stage * STAGE + A_ELEMS + wave * (BN_ / 8) * BK;
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sb + i * 8 * BK), 16, 0, 0);
+    };
+
+    const int sw = (r15 >> 1) & 7;
+    const int k_off0 = ((g ^ sw) << 3), k_off1 = (((4 + g) ^ sw) << 3);
+    const int a_rd = (wr * (BM2 / WM) + r15) * BK;
+    const int b_rd = A_ELEMS + (wc * (BN_ / WN) + r15) * BK;
+
+    f32x4 acc[TM][TN];
+    f16x8 af[TM], bf[TN];
+#define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
+#define CGPT_SLOT_END CGPT_FENCE __builtin_amdgcn_s_barrier(); CGPT_FENCE
+
+    const int nk = p.K / BK;
+    int c = 0;
+    int t = blockIdx.x;
+    if (t < ntiles) { set_tile(t); load_a(0, 0); load_b(0, 0); }
+    for (; t < ntiles; t += gridDim.x) {
+        f32x4 bias4[TN];
+        {
+            const int nb0 = tn * BN_ + wc * (BN_ / WN) + 4 * g;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && nb0 + j * 16 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + j * 16);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                               // K-tile 0 of this tile has landed; both halves aligned
+        if (late) { CGPT_SLOT_END }                    // the late half enters one slot behind
+
+        for (int kt = 0; kt < nk; ++kt, ++c) {
+            const half_t* st = smem3 + (c & 1) * STAGE;
+            const bool more = kt + 1 < nk;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int ks = (NQ == 4) ? (q >> 1) : q;
+                const int ko = ks ? k_off1 : k_off0;
+                const int h0 = (NQ == 4) ? ((q == 0 || q == 3) ? 0 : 1) : 0;    // first M-half of this phase
+                const int nh = (NQ == 4) ? 1 : 2;                                // M-halves per phase
+                // ---------------- L(q): fragment reads (+ the LDS-DMA requests of the next K-tile)
+                if (NQ == 2 || q == 0 || q == 2) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + ko);
+                }
+#pragma unroll
+                for (int i = 0; i < nh * HM; ++i)
+                    af[h0 * HM + i] = *reinterpret_cast<const f16x8*>(st + a_rd + (h0 * HM + i) * 16 * BK + ko);
+                if (more && !(p.ablate & 1)) {
+                    if (q == 0) load_a((c + 1) & 1, kt + 1);
+                    if ((NQ == 4 && q == 1) || (NQ == 2 && q == 0)) load_b((c + 1) & 1, kt + 1);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (q == NQ - 1 && late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CGPT_SLOT_END
+                // ---------------- M(q): 16 * nh MFMAs
+#pragma unroll
+                for (int i = 0; i < nh * HM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[h0 * HM + i][j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[h0 * HM + i], acc[h0 * HM + i][j], 0, 0, 0);
+                if (q == NQ - 1 && !late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CGPT_SLOT_END
+            }
+        }
+        if (!late) { CGPT_SLOT_END }                   // the early half waits one slot for its partners' last M
+
+        const int etm = tm, etn = tn;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
+        if (t + (int)gridDim.x < ntiles) { set_tile(t + gridDim.x); load_a(c & 1, 0); load_b(c & 1, 0); }
+        gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g,
+                                      (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2));
+    }
+#undef CGPT_FENCE
+#undef CGPT_SLOT_END
+}
+
+template <int EPI, int NQ>
+hipError_t launch_v3(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_f16_kernel<EPI, NQ>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = tiles < num_cus ? tiles : num_cus;
+    hipLaunchKernelGGL((gemm3_f16_kernel<EPI, NQ>), dim3(grid), dim3(512), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+template <int NQ>
+hipError_t launch_v3_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
+    switch (epilogue) {
+        case EPI_F16: return launch_v3<EPI_F16, NQ>(p, stream);
+        case EPI_F16_GELU: return launch_v3<EPI_F16_GELU, NQ>(p, stream);
+        case EPI_F32: return launch_v3<EPI_F32, NQ>(p, stream);
+        case EPI_RESID: return launch_v3<EPI_RESID, NQ>(p, stream);
+        case EPI_PATCH: return launch_v3<EPI_PATCH, NQ>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ v4
+// 256x256 tile, K-steps of 32 in an NS-deep ring of 32-KiB LDS stages (NS = 4: 128 KiB), LDS-DMA requests running
+// D = NS-1 sub-tiles ahead behind a COUNTED s_waitcnt vmcnt (never 0 in steady state), phase-alternating halves as v3.
+// Why: with two 64-KiB stages a request has ~0.8 us to land, but under streaming load an LDS-DMA piece takes ~1.1 us
+// issue->landed (MI355X guide, ldsdma-fill); removing the in-loop loads from v3 took the fc2 GEMM from 861 to 659 us.
+//   LDS image of a stage: A [256 rows][32 halfs] then W [256][32]; a row is 64 B, so a 256-B bank row holds 4 tile rows.
+//   16-byte chunk c of row r sits at position c ^ ((-(r >> 2)) & 3): with it the 16 rows x one chunk of a fragment read
+//   hit 16 distinct 16-B slots for each of gfx950's ds_read_b128 lane groups (which mix chunk g and g+1).
+//   One LDS-DMA piece = 1 KiB = 16 rows x 64 B; lane l -> row l>>2, position l&3, source chunk (l&3) ^ ((-(l>>4)) & 3).
+//   Wave w requests A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of every sub-tile (4 requests per sub-tile per wave).
+// Per sub-tile s (32 MFMAs per wave):  L(s): 12 fragment reads, 4 requests for sub-tile s+D, lgkmcnt(0) | barrier |
+// M(s): 32 MFMAs | barrier; waves 4-7 run one slot behind waves 0-3.  Before the barrier that ends the slot in which the
+// early half computes M(s), every wave has retired its own requests for sub-tile s+1 (counted vmcnt leaves the D-1 younger
+// groups in flight), so after that barrier sub-tile s+1 is visible to everybody.  A stage is re-requested D-NS = -1 sub-tile
+// ... i.e. the stage of sub-tile s+D last held sub-tile s-1, whose reads both halves retired (lgkmcnt(0) before a barrier)
+// at least one full slot earlier.
+template <int EPI, int NS>
+__global__ __launch_bounds__(512, 2) void gemm4_f16_kernel(GemmParams p) {
+    constexpr int BM2 = 256, BN_ = 256, WN = 4, WM = 2, BK4 = 32;
+    constexpr int TM = 8, TN = 4;
+    constexpr int A_ELEMS = BM2 * BK4, STAGE = (BM2 + BN_) * BK4;     // halfs
+    constexpr int D = NS - 1;
+    extern __shared__ __attribute__((aligned(16))) half_t smem4[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const bool late = wave >= 4;
+    const int r15 = lane & 15, g = lane >> 4;
+
+    const int tiles_m = (p.M + BM2 - 1) / BM2;
+    const int tiles_n = (p.N + BN_ - 1) / BN_;
+    const int ntiles = tiles_m * tiles_n;
+
+    // LDS-DMA sources: piece pc (0,1) of this wave covers tile rows (2*wave + pc)*16 + (lane>>2)
+    const int prow = lane >> 2;
+    const int psrc = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) << 3;          // source chunk (halfs) for this lane
+    const half_t* a_src[2];
+    const half_t* b_src[2];
+    int tm = 0, tn = 0;
+    auto set_tile = [&](int t) {
+        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            const int r = (2 * wave + pc) * 16 + prow;
+            a_src[pc] = p.A + (int64_t)(tm * BM2 + r) * p.lda + psrc;
+            b_src[pc] = p.W + (int64_t)(tn * BN_ + r) * p.ldw + psrc;
+        }
+    };
+    auto request = [&](int stage, int s) {                                  // 4 LDS-DMA pieces of sub-tile s
+        half_t* sa = smem4 + stage * STAGE + (2 * wave) * 16 * BK4;
+        half_t* sb = sa + A_ELEMS;
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[pc] + s * BK4),
+                                             (__attribute__((address_space(3))) void*)(sa + pc * 16 * BK4), 16, 0, 0);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[pc] + s * BK4),
+                                             (__attribute__((address_space(3))) void*)(sb + pc * 16 * BK4), 16, 0, 0);
+    };
+
+    const int rsw = ((g ^ ((0 - (r15 >> 2)) & 3)) << 3);                    // swizzled chunk offset of this lane's fragment
+    const int a_rd = (wr * (BM2 / WM) + r15) * BK4 + rsw;
+    const int b_rd = A_ELEMS + (wc * (BN_ / WN) + r15) * BK4 + rsw;
+
+    f32x4 acc[TM][TN];
+    f16x8 af[TM], bf[TN];
+#define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
+#define CGPT_SLOT_END CGPT_FENCE __builtin_amdgcn_s_barrier(); CGPT_FENCE
+    // retire this wave's requests for the sub-tile that is `younger` groups behind the newest one (4 requests per group)
+#define CGPT_RETIRE(younger)                                                       \
+    do {                                                                           \
+        if ((younger) >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      \
+        else if ((younger) == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  \
+        else if ((younger) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
+    } while (0)
+
+    const int ns = p.K / BK4;
+    int c = 0;                                     // running sub-tile counter: sub-tile lives in stage c % NS
+    int t = blockIdx.x;
+    if (t < ntiles) {
+        set_tile(t);
+        for (int s = 0; s < D && s < ns; ++s) request(s % NS, s);
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        f32x4 bias4[TN];
+        {
+            const int nb0 = tn * BN_ + wc * (BN_ / WN) + 4 * g;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && nb0 + j * 16 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + j * 16);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // sub-tile 0 (requested before the previous epilogue / at kernel start) must be visible: the previous tile's
+        // stores and the bias loads are younger than those requests, so only vmcnt(0) is exact here.
+        __syncthreads();
+        if (late) { CGPT_SLOT_END }
+
+        for (int s = 0; s < ns; ++s, ++c) {
+            const half_t* st = smem4 + (c % NS) * STAGE;
+            // ---------------- L(s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK4);
+            if (s + D < ns && !(p.ablate & 1)) request((c + D) % NS, s + D);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // groups younger than the one of sub-tile s+1: sub-tiles s+2 .. min(s+D, ns-1)
+            const int younger = (s + D < ns ? s + D : ns - 1) - (s + 1);
+            if (late && s + 1 < ns) CGPT_RETIRE(younger);
+            CGPT_SLOT_END
+            // ---------------- M(s): 32 MFMAs
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            if (!late && s + 1 < ns) CGPT_RETIRE(younger);
+            CGPT_SLOT_END
+        }
+        if (!late) { CGPT_SLOT_END }
+
+        const int etm = tm, etn = tn;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
+        if (t + (int)gridDim.x < ntiles) {
+            set_tile(t + gridDim.x);
+            for (int s = 0; s < D && s < ns; ++s) request((c + s) % NS, s);
+        }
+        gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g,
+                                      (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2));
+    }
+#undef CGPT_FENCE
+#undef CGPT_SLOT_END
+#undef CGPT_RETIRE
+}
+
+template <int EPI, int NS>
+hipError_t launch_v4(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds_bytes = NS * (256 + 256) * 32 * (int)sizeof(half_t);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_f16_kernel<EPI, NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = tiles < num_cus ? tiles : num_cus;
+    hipLaunchKernelGGL((gemm4_f16_kernel<EPI, NS>), dim3(grid), dim3(512), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+template <int NS>
+hipError_t launch_v4_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
+    switch (epilogue) {
+        case EPI_F16: return launch_v4<EPI_F16, NS>(p, stream);
+        case EPI_F16_GELU: return launch_v4<EPI_F16_GELU, NS>(p, stream);
+        case EPI_F32: return launch_v4<EPI_F32, NS>(p, stream);
+        case EPI_RESID: return launch_v4<EPI_RESID, NS>(p, stream);
+        case EPI_PATCH: return launch_v4<EPI_PATCH, NS>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 }  // namespace
 
 int g_gemm_kernel = 0;
 int g_gemm_ablate = 0;
+unsigned long long* g_gemm_dbg = nullptr;
 
 hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.ablate = g_gemm_ablate;
+    p.dbg = g_gemm_dbg;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
         return hipErrorInvalidValue;
     // Kernel choice (speed only).  v2 needs A readable for round_up(M,256) rows and W for round_up(N,256) rows: the
@@ -453,10 +919,16 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     const int force = vec_ok ? g_gemm_kernel : 1;   // 0 auto, 1 v1 (128x128), 2 v2 BN=256, 3 v2 BN=128  (cgpt_set_option)
     if (force == 2) return launch_v2_epi<256>(epilogue, p, stream);   // W must be readable for round_up(N,256) rows
     if (force == 3 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
+    if (force == 4) return launch_v3_epi<4>(epilogue, p, stream);
+    if (force == 5) return launch_v3_epi<2>(epilogue, p, stream);
+    if (force == 6) return launch_v4_epi<4>(epilogue, p, stream);
+    if (force == 7) return launch_v4_epi<5>(epilogue, p, stream);
     if (force == 0 && p.M >= 1024) {
-        // measured on MI355X (profiles/r01/gemm_ab_*.txt): the 256x256 direct-to-LDS kernel wins on every ViT / Q-Former
-        // shape at M >= 3341, also when N is not a multiple of 256 (N padded: weights are allocated with 256-row padding).
-        return launch_v2_epi<256>(epilogue, p, stream);
+        // measured on MI355X (profiles/r01/gemm_variants.txt): the 256x256 direct-to-LDS tile wins on every ViT / Q-Former
+        // shape, also when N is not a multiple of 256 (weights are allocated with 256-row padding); among the 256x256
+        // schedules the phase-alternating v3 with 4 phases per K-tile is the fastest inside the model (8.17 vs 7.95 img/s
+        // for v2; the 32-deep-K ring v4 is correct but slower).
+        return launch_v3_epi<4>(epilogue, p, stream);
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

@@ -625,13 +625,16 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
     if (!key) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: null key");
     const std::string k(key);
     if (k == "gemm_kernel") {
-        if (value < 0 || value > 3) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_kernel must be 0..3");
+        if (value < 0 || value > 7) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_kernel must be 0..7");
         g_gemm_kernel = value;
         return CGPT_OK;
     }
     if (k == "gemm_ablate") { g_gemm_ablate = value; return CGPT_OK; }   // measurement only (wrong results)
     return cgpt_fail(CGPT_ERR_NOT_FOUND, "cgpt_set_option: unknown option '" + k + "'");
 }
+
+// diagnostic builds only: device buffer receiving per-wave cycle sums of the GEMM (not part of include/cgpt.h)
+cgpt_status cgpt_debug_set_gemm_stamps(void* dev_buf) { g_gemm_dbg = (unsigned long long*)dev_buf; return CGPT_OK; }
 
 cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on) {
     if (!h) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_profile_enable: null handle");
