@@ -13,8 +13,18 @@
 //   so MFMA k-slot 8g+j stands for key 32u + 4g + j (j<4) or 32u + 16 + 4g + (j-4); the matching V B-fragment
 //   (rows = those keys, col = d) is fetched from the ROW-major LDS image of V by two ds_read_b64_tr_b16
 //   (4 rows x 16 columns per 16-lane group, transposed in hardware).
-// LDS row strides: K 208 B (13 x 16 B: the 16 rows of a ds_read_b128 fragment land on distinct 16-B slots),
-// V 224 B / 160 B (the 8 rows a 32-lane half reads by ds_read_b64_tr_b16 land on distinct 32-B bank ranges).
+//
+// Latency structure (round-1 profile: 58 % of wave cycles parked, hipcc had scheduled read -> wait -> 1-2 MFMAs):
+//   * K / V fragments travel through explicit register rings (K: 4 key tiles ahead, V: 2 key pairs ahead) with
+//     sched_barrier fences, so the compiler's counted lgkmcnt waits leave the younger reads in flight;
+//   * staging is fully unrolled: all of a thread's K and V global loads are issued at once; K goes to LDS first, V is
+//     written to LDS only after the wave's first QK^T + softmax (its load latency hides under them).
+//   * workgroups are persistent (one per CU, LDS-limited) and walk (sample, head) items: the NEXT item's K and V are
+//     requested into registers as soon as the current V has been written to LDS, and the next tile's Q one tile ahead, so
+//     the HBM phase of item i+1 overlaps the MFMA / softmax phase of item i (before: all CUs staged, then all computed).
+// LDS images: K rows are DPAD halfs with NO padding and a chunk swizzle that is conflict-free for gfx950's
+// ds_read_b128 lane groups (192-B rows: chunk 4ds+g -> 4ds + (g ^ ((-(row>>2))&3)); 128-B rows: c ^ ((row>>1)&7));
+// V rows have stride 224 B / 160 B: the 8 rows a 32-lane half reads by ds_read_b64_tr_b16 land on distinct 32-B windows.
 #include "kernels.h"
 
 namespace cgpt {
@@ -32,74 +42,106 @@ __device__ __forceinline__ f16x4 lds_read_tr16(const half_t* p) {
 }
 
 template <int DPAD> struct AttnLayout {
-    static constexpr int KSTR = DPAD + 8;                   // halfs
+    static constexpr int KROW = DPAD;                       // halfs, swizzled, unpadded
     static constexpr int VSTR = (DPAD == 96) ? 112 : 80;    // halfs
 };
 
-// HD: head_dim (88 | 64); DPAD: HD rounded up to 32; NKT: number of 16-key tiles held (keys padded to NKT*16).
-template <int HD, int DPAD, int NKT>
-__global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int KSTR = AttnLayout<DPAD>::KSTR, VSTR = AttnLayout<DPAD>::VSTR;
-    constexpr int TKP = NKT * 16;
-    constexpr int CH = DPAD / 8;
-    half_t* Ks = reinterpret_cast<half_t*>(smem_raw);
-    half_t* Vs = Ks + TKP * KSTR;
+template <int DPAD> __device__ __forceinline__ int k_chunk_pos(int row, int ch) {
+    if constexpr (DPAD == 96) return (ch & ~3) | ((ch & 3) ^ ((0 - (row >> 2)) & 3));
+    else return ch ^ ((row >> 1) & 7);
+}
 
-    const int h = blockIdx.x, b = blockIdx.y;
+#define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
+
+// HD: head_dim (88 | 64); DPAD: HD rounded up to 32; NKT: 16-key tiles held (keys padded to NKT*16); NT: threads.
+template <int HD, int DPAD, int NKT, int NT>
+__global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int KROW = AttnLayout<DPAD>::KROW, VSTR = AttnLayout<DPAD>::VSTR;
+    constexpr int TKP = NKT * 16;
+    constexpr int CH = DPAD / 8, NDS = DPAD / 32, NDT = DPAD / 16;
+    constexpr int NV = (TKP * CH + NT - 1) / NT;            // staging items per thread
+    constexpr int NWAVES = NT / 64;
+    half_t* Ks = reinterpret_cast<half_t*>(smem_raw);
+    half_t* Vs = Ks + TKP * KROW;
+
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwaves = blockDim.x >> 6;
     const int r15 = lane & 15, g = lane >> 4;
+    const int nitems = p.heads * p.B;
 
-    // ---- stage K and V of this (sample, head): zero-fill d >= HD and keys >= Tk
-    const half_t* Kg = p.K + (int64_t)b * p.kv_batch_stride + h * HD;
-    const half_t* Vg = p.V + (int64_t)b * p.kv_batch_stride + h * HD;
-    for (int idx = tid; idx < TKP * CH; idx += blockDim.x) {
-        const int row = idx / CH, ch = idx - row * CH;
-        f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < p.Tk && ch * 8 < HD) {
-            kv = *reinterpret_cast<const f16x8*>(Kg + (int64_t)row * p.ldk + ch * 8);
-            vv = *reinterpret_cast<const f16x8*>(Vg + (int64_t)row * p.ldv + ch * 8);
+    // ---- staging registers: this thread's NV 16-byte pieces of K (or V) of one (sample, head) item.
+    // Loads are UNCONDITIONAL from clamped addresses (a guarded load becomes its own basic block with a vmcnt wait at the
+    // join, which serialises the whole staging); the zero fill is a select applied when the piece is written to LDS.
+    // ONE register set serves both operands alternately: K of the next item is requested while the current item computes,
+    // V of the current item right after its K has gone to LDS (it lands under the first QK^T + softmax).
+    f16x8 sreg[NV];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto request_kv = [&](int item, bool want_v) {
+        const int hh = item % p.heads, bb = item / p.heads;
+        const half_t* G = (want_v ? p.V : p.K) + (int64_t)bb * p.kv_batch_stride + hh * HD;
+        const int64_t ldg = want_v ? p.ldv : p.ldk;
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int idx = tid + it * NT;
+            const int row = min(idx / CH, p.Tk - 1), ch = min(idx % CH, HD / 8 - 1);
+            sreg[it] = *reinterpret_cast<const f16x8*>(G + (int64_t)row * ldg + ch * 8);
         }
-        *reinterpret_cast<f16x8*>(Ks + row * KSTR + ch * 8) = kv;
-        *reinterpret_cast<f16x8*>(Vs + row * VSTR + ch * 8) = vv;
-    }
-    __syncthreads();
+    };
 
     const float sl2 = p.scale * 1.44269504088896340736f;   // softmax(scale*s) = 2^((s - max) * scale * log2 e) / sum
     const int nqt = (p.Tq + 15) >> 4;
-    const half_t* Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
-    half_t* Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
+    const half_t* Qb = nullptr;
+    half_t* Ob = nullptr;
 
-    for (int qt = wave; qt < nqt; qt += nwaves) {
-        // K/V fragments do not depend on the query tile: without this opaque zero the compiler hoists all
-        // 54 + 108 LDS reads out of the loop and spills.  (cdna guide section 5.7 item 3)
+    f32x4 s[NKT];
+    float sum = 1.f;
+    f16x8 qf[NDS], qnext[NDS];
+    // Q^T B-fragments of query tile qt: lane holds Q[query r15][d = 32*ds + 8*g .. +7] (zero beyond HD)
+    auto request_q = [&](int qt) {
+        const int qrow = min(qt * 16 + r15, p.Tq - 1);
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            const int d = min(ds * 32 + g * 8, HD - 8);
+            qnext[ds] = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
+        }
+    };
+    auto take_q = [&]() {
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) qf[ds] = (ds * 32 + g * 8 < HD) ? qnext[ds] : zero8;
+    };
+
+    // S^T = K . Q^T for the query tile in qf, then the softmax numerators in s[] and the row sums in `sum`.
+    auto qk_softmax = [&]() {
+        // K fragments do not depend on the query tile: an opaque zero keeps the compiler from hoisting them out of the loop
         int opq = 0;
         asm volatile("" : "+v"(opq));
         const half_t* Kq = Ks + opq;
-        const half_t* Vq = Vs + opq;
-        // Q^T B-fragments: lane holds Q[query r15][d = 32*ds + 8*g .. +7]
-        const int qrow = min(qt * 16 + r15, p.Tq - 1);
-        f16x8 qf[DPAD / 32];
+        // this lane's fragment of key tile kt, k-step ds: row kt*16 + r15, chunk 4ds + g (swizzled)
+        auto kaddr = [&](int kt, int ds) {
+            const int row = kt * 16 + r15;
+            return Kq + row * KROW + k_chunk_pos<DPAD>(row, ds * 4 + g) * 8;
+        };
+        constexpr int KD = (NKT > 2) ? 2 : NKT - 1;                 // key tiles in flight ahead of the MFMAs
+        f16x8 kring[KD + 1][NDS];
 #pragma unroll
-        for (int ds = 0; ds < DPAD / 32; ++ds) {
-            const int d = ds * 32 + g * 8;
-            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (d < HD) v = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
-            qf[ds] = v;
-        }
-        // S^T = K . Q^T
-        f32x4 s[NKT];
+        for (int kt = 0; kt < KD && kt < NKT; ++kt)
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) kring[kt % (KD + 1)][ds] = *reinterpret_cast<const f16x8*>(kaddr(kt, ds));
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
+            if (kt + KD < NKT) {
+#pragma unroll
+                for (int ds = 0; ds < NDS; ++ds)
+                    kring[(kt + KD) % (KD + 1)][ds] = *reinterpret_cast<const f16x8*>(kaddr(kt + KD, ds));
+            }
+            CGPT_FENCE
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ds = 0; ds < DPAD / 32; ++ds) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(Kq + (kt * 16 + r15) * KSTR + ds * 32 + g * 8);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ds], acc, 0, 0, 0);
-            }
+            for (int ds = 0; ds < NDS; ++ds)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kring[kt % (KD + 1)][ds], qf[ds], acc, 0, 0, 0);
             s[kt] = acc;
+            CGPT_FENCE
         }
         // softmax over keys (all keys of a query: this lane's registers x the 4 lanes sharing r15)
         float mx = -1e30f;
@@ -116,25 +158,48 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
+        const float mxs = mx * sl2;
+        float sm = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = exp2f((s[kt][r] - mx) * sl2);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, -mxs));
                 s[kt][r] = e;
-                sum += e;
+                if constexpr (DPAD == HD) sm += e;
             }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        if constexpr (DPAD == HD) {
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            sum = sm;
+        }
+    };
 
-        // O = P . V
-        f32x4 o[DPAD / 16];
+    // O = P . V for query tile qt from s[] / sum, normalised and stored.
+    auto pv_store = [&](int qt) {
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
+        const half_t* vbase = Vs + opq + (4 * g + (r15 >> 2)) * VSTR + 4 * (r15 & 3);
+        f32x4 o[NDT];
 #pragma unroll
-        for (int dt = 0; dt < DPAD / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const half_t* vbase = Vq + (4 * g + (r15 >> 2)) * VSTR + 4 * (r15 & 3);
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int NU = NKT / 2;
+        constexpr int VD = (NU > 1) ? 1 : NU - 1;                   // key pairs in flight ahead of the MFMAs
+        f16x4 vring[VD + 1][NDT][2];
+        auto vload = [&](int u, int slot) {
 #pragma unroll
-        for (int u = 0; u < NKT / 2; ++u) {
+            for (int dt = 0; dt < NDT; ++dt) {
+                const half_t* a1 = vbase + (32 * u) * VSTR + dt * 16;
+                vring[slot][dt][0] = lds_read_tr16(a1);
+                vring[slot][dt][1] = lds_read_tr16(a1 + 16 * VSTR);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < VD && u < NU; ++u) vload(u, u % (VD + 1));
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + VD < NU) vload(u + VD, (u + VD) % (VD + 1));
+            CGPT_FENCE
             f16x8 pf;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -142,45 +207,108 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
                 pf[4 + j] = (half_t)s[2 * u + 1][j];
             }
 #pragma unroll
-            for (int dt = 0; dt < DPAD / 16; ++dt) {
-                const half_t* a1 = vbase + (32 * u) * VSTR + dt * 16;
-                const f16x4 v1 = lds_read_tr16(a1);
-                const f16x4 v2 = lds_read_tr16(a1 + 16 * VSTR);
+            for (int dt = 0; dt < NDT; ++dt) {
+                const f16x4 v1 = vring[u % (VD + 1)][dt][0], v2 = vring[u % (VD + 1)][dt][1];
                 const f16x8 vf = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o[dt], 0, 0, 0);
+                // operands swapped: O^T tile, row = d (4g + r), col = query (lane & 15): a lane owns 4 consecutive d of ONE query
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
             }
+            CGPT_FENCE
         }
-        // O tile: col d = lane&15, row (query) = 4g + r.  1/sum of query q sits in lanes with r15 == q.
-        const float inv = 1.0f / sum;
+        float den = sum;                               // DPAD == HD: VALU row sum (lane-local for query r15)
+        if constexpr (DPAD > HD) {                     // row HD of O^T: d-tile HD/16, g = (HD%16)/4, reg (HD%16)%4
+            constexpr int DT = HD / 16, GG = (HD % 16) / 4, RR = (HD % 16) % 4;
+            den = __shfl(o[DT][RR], 16 * GG + r15);
+        }
+        const float inv = 1.0f / den;
+        const int q = qt * 16 + r15;
+        if (q < p.Tq) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float invr = __shfl(inv, 4 * g + r);
-            const int q = qt * 16 + 4 * g + r;
-            if (q < p.Tq) {
-#pragma unroll
-                for (int dt = 0; dt < DPAD / 16; ++dt) {
-                    const int d = dt * 16 + r15;
-                    if (d < HD) Ob[(int64_t)q * p.ldo + d] = (half_t)(o[dt][r] * invr);
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int d0 = dt * 16 + 4 * g;
+                if (d0 < HD) {
+                    const f16x4 hv = {(half_t)(o[dt][0] * inv), (half_t)(o[dt][1] * inv), (half_t)(o[dt][2] * inv),
+                                      (half_t)(o[dt][3] * inv)};
+                    *reinterpret_cast<f16x4*>(Ob + (int64_t)q * p.ldo + d0) = hv;
                 }
             }
         }
+    };
+
+    // ---- persistent walk over (sample, head) items
+    int item = blockIdx.x;
+    if (item < nitems) request_kv(item, false);
+    for (; item < nitems; item += gridDim.x) {
+        const int h = item % p.heads, b = item / p.heads;
+        Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
+        Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
+        int qt = wave;
+        const bool have = qt < nqt;
+        if (have) request_q(qt);
+        // K of this item: registers -> swizzled LDS image
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx / CH, ch = idx - row * CH;
+            const bool valid = row < p.Tk && ch * 8 < HD;
+            if (idx < TKP * CH) *reinterpret_cast<f16x8*>(Ks + row * KROW + k_chunk_pos<DPAD>(row, ch) * 8) = valid ? sreg[it] : zero8;
+        }
+        __syncthreads();
+        request_kv(item, true);                          // V of this item; lands under the first QK^T + softmax
+        // first query tile of every wave: QK^T + softmax run before V is needed in LDS
+        if (have) {
+            take_q();
+            if (qt + NWAVES < nqt) request_q(qt + NWAVES);
+            qk_softmax();
+        }
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx / CH, ch = idx - row * CH;
+            const bool valid = row < p.Tk && ch * 8 < HD;
+            f16x8 vv = valid ? sreg[it] : zero8;
+            // the padding column d = HD carries 1.0: the P.V MFMAs then also produce sum_k P[q][k] (the softmax denominator,
+            // from the same fp16-rounded P as the numerator) in row HD of O^T -- no VALU sum pass.  Padding keys have P = 0.
+            if (DPAD > HD && ch * 8 == HD) vv = f16x8{(half_t)1.0f, 0, 0, 0, 0, 0, 0, 0};
+            if (idx < TKP * CH) *reinterpret_cast<f16x8*>(Vs + row * VSTR + ch * 8) = vv;
+        }
+        __syncthreads();
+        // the staging registers are free: request the NEXT item's K now; it lands during the rest of this item
+        if (item + (int)gridDim.x < nitems) request_kv(item + gridDim.x, false);
+        if (have) pv_store(qt);
+        for (qt += NWAVES; qt < nqt; qt += NWAVES) {
+            take_q();
+            if (qt + NWAVES < nqt) request_q(qt + NWAVES);
+            qk_softmax();
+            pv_store(qt);
+        }
+        __syncthreads();                               // every wave is done with this item's LDS images
     }
 }
 
-template <int HD, int DPAD, int NKT>
+#undef CGPT_FENCE
+
+template <int HD, int DPAD, int NKT, int NT>
 hipError_t launch_one(const AttnParams& p, hipStream_t stream) {
-    constexpr int lds_bytes = NKT * 16 * (AttnLayout<DPAD>::KSTR + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
+    constexpr int lds_bytes = NKT * 16 * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
     static bool configured = false;   // per instantiation; the attribute is idempotent
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, DPAD, NKT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, DPAD, NKT, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    const int nqt = (p.Tq + 15) / 16;
-    const int waves = nqt >= 8 ? 8 : (nqt >= 4 ? 4 : (nqt >= 2 ? 2 : 1));
-    dim3 grid(p.heads, p.B), block(64 * waves);
-    hipLaunchKernelGGL((attention_kernel<HD, DPAD, NKT>), grid, block, lds_bytes, stream, p);
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int items = p.heads * p.B;
+    const int per_cu = lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 40 * 1024 ? 2 : 4);     // resident workgroups per CU (LDS)
+    const int grid = items < num_cus * per_cu ? items : num_cus * per_cu;
+    hipLaunchKernelGGL((attention_kernel<HD, DPAD, NKT, NT>), dim3(grid), dim3(NT), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
@@ -191,8 +319,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8)) return hipErrorInvalidValue;   // 16-byte row alignment
     const bool small = p.Tk <= 32;
     if (p.Tk > 288) return hipErrorInvalidValue;   // whole-K/V-in-LDS design: T <= 288 (224^2 images; 448^2 is "next")
-    if (p.head_dim == 88) return small ? launch_one<88, 96, 2>(p, stream) : launch_one<88, 96, 18>(p, stream);
-    if (p.head_dim == 64) return small ? launch_one<64, 64, 2>(p, stream) : launch_one<64, 64, 18>(p, stream);
+    if (p.head_dim == 88) return small ? launch_one<88, 96, 2, 128>(p, stream) : launch_one<88, 96, 18, 512>(p, stream);
+    if (p.head_dim == 64) return small ? launch_one<64, 64, 2, 128>(p, stream) : launch_one<64, 64, 18, 512>(p, stream);
     return hipErrorInvalidValue;
 }
 
