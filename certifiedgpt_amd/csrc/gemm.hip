@@ -901,6 +901,198 @@ hipError_t launch_v4_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
     }
 }
 
+// v5 = v3 (4 phases) with the fragment reads running ONE PHASE AHEAD of the MFMAs that consume them (double-buffered A and
+// W fragments), so that no L segment ends on an exposed LDS round trip: measured on v3, an L segment (reads + ~200-cycle LDS
+// latency + 4 LDS-DMA issues) takes ~400 cycles against the 256 cycles of the partner's 16 MFMAs.
+//   L0: read A(q0)->A0, W(k0)->W0 | 3 DMA pieces | read A(q1)->A1 | lgkmcnt(4)  (A0, W0 landed; they had the DMA issue time)
+//   L1: read A(q2)->A0, W(k1)->W1 | 3 DMA pieces | lgkmcnt(8)                   (A1 landed)
+//   L2: read A(q3)->A1            | 2 DMA pieces | lgkmcnt(4)                   (A0, W1 landed)
+//   L3:                                            lgkmcnt(0)                   (A1 landed)
+// The reads of a stage end in L2, two phases before the K-tile boundary; the stage is re-requested one K-tile later.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm5_f16_kernel(GemmParams p) {
+    constexpr int NQ = 4;
+    constexpr int BM2 = 256, BN_ = 256, WN = 4, WM = 2;
+    constexpr int TM = 8, TN = 4, HM = 4;
+    constexpr int A_ELEMS = BM2 * BK, B_ELEMS = BN_ * BK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int A_INSTR = 4, B_INSTR = 4;
+    extern __shared__ __attribute__((aligned(16))) half_t smem5[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const bool late = wave >= 4;                       // the half that runs one slot behind
+    const int r15 = lane & 15, g = lane >> 4;
+
+    const int tiles_m = (p.M + BM2 - 1) / BM2;
+    const int tiles_n = (p.N + BN_ - 1) / BN_;
+    const int ntiles = tiles_m * tiles_n;
+
+    const int lr = lane >> 3, cpos = lane & 7;
+    const half_t* a_src[A_INSTR];
+    const half_t* b_src[B_INSTR];
+    int tm = 0, tn = 0;
+    auto set_tile = [&](int t) {
+        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn);
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int r = wave * (BM2 / 8) + i * 8 + lr;
+            a_src[i] = p.A + (int64_t)(tm * BM2 + r) * p.lda + ((cpos ^ ((r >> 1) & 7)) << 3);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int r = wave * (BN_ / 8) + i * 8 + lr;
+            b_src[i] = p.W + (int64_t)(tn * BN_ + r) * p.ldw + ((cpos ^ ((r >> 1) & 7)) << 3);
+        }
+    };
+    // LDS-DMA piece i of this wave (0-3: A rows, 4-7: W rows) of K-tile kt into `stage`
+    auto request_piece = [&](int stage, int kt, int i) {
+        if (i < 4) {
+            half_t* sa = smem5 + stage * STAGE + wave * (BM2 / 8) * BK + i * 8 * BK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)sa, 16, 0, 0);
+        } else {
+            half_t* sb = smem5 + stage * STAGE + A_ELEMS + wave * (BN_ / 8) * BK + (i - 4) * 8 * BK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i - 4] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)sb, 16, 0, 0);
+        }
+    };
+    auto request_all = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) request_piece(stage, kt, i);
+    };
+    const int sw = (r15 >> 1) & 7;
+    const int k_off0 = ((g ^ sw) << 3), k_off1 = (((4 + g) ^ sw) << 3);
+    const int a_rd = (wr * (BM2 / WM) + r15) * BK;
+    const int b_rd = A_ELEMS + (wc * (BN_ / WN) + r15) * BK;
+
+    f32x4 acc[TM][TN];
+    f16x8 fa0[HM], fa1[HM], fw0[TN], fw1[TN];
+#define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
+#define CGPT_SLOT_END CGPT_FENCE __builtin_amdgcn_s_barrier(); CGPT_FENCE
+
+    const int nk = p.K / BK;
+    int c = 0;
+    int t = blockIdx.x;
+    if (t < ntiles) { set_tile(t); request_all(0, 0); }
+    for (; t < ntiles; t += gridDim.x) {
+        f32x4 bias4[TN];
+        {
+            const int nb0 = tn * BN_ + wc * (BN_ / WN) + 4 * g;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && nb0 + j * 16 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + j * 16);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                               // K-tile 0 of this tile has landed; both halves aligned
+        if (late) { CGPT_SLOT_END }                    // the late half enters one slot behind
+
+        for (int kt = 0; kt < nk; ++kt, ++c) {
+            const half_t* st = smem5 + (c & 1) * STAGE;
+            const bool more = kt + 1 < nk;
+            const bool req = more && !(p.ablate & 1);
+            const int nxs = (c + 1) & 1;
+#define CGPT_RD_A(dst, h_, ko_)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                            \
+        dst[i] = *reinterpret_cast<const f16x8*>(st + a_rd + ((h_) * HM + i) * 16 * BK + (ko_));
+#define CGPT_RD_W(dst, ko_)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + (ko_));
+#define CGPT_MMQ(fa_, fw_, h_)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                        \
+            acc[(h_) * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw_[j], fa_[i], acc[(h_) * HM + i][j], 0, 0, 0);
+            // ---- L0
+            CGPT_RD_A(fa0, 0, k_off0)
+            CGPT_RD_W(fw0, k_off0)
+            CGPT_FENCE
+            if (req) { request_piece(nxs, kt + 1, 0); request_piece(nxs, kt + 1, 1); request_piece(nxs, kt + 1, 2); }
+            CGPT_FENCE
+            CGPT_RD_A(fa1, 1, k_off0)
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            CGPT_SLOT_END
+            CGPT_MMQ(fa0, fw0, 0)                     // M0: (k0, h0)
+            CGPT_SLOT_END
+            // ---- L1
+            CGPT_RD_A(fa0, 1, k_off1)
+            CGPT_RD_W(fw1, k_off1)
+            CGPT_FENCE
+            if (req) { request_piece(nxs, kt + 1, 3); request_piece(nxs, kt + 1, 4); request_piece(nxs, kt + 1, 5); }
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            CGPT_SLOT_END
+            CGPT_MMQ(fa1, fw0, 1)                     // M1: (k0, h1)
+            CGPT_SLOT_END
+            // ---- L2
+            CGPT_RD_A(fa1, 0, k_off1)
+            CGPT_FENCE
+            if (req) { request_piece(nxs, kt + 1, 6); request_piece(nxs, kt + 1, 7); }
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            CGPT_SLOT_END
+            CGPT_MMQ(fa0, fw1, 1)                     // M2: (k1, h1)
+            CGPT_SLOT_END
+            // ---- L3
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CGPT_SLOT_END
+            CGPT_MMQ(fa1, fw1, 0)                     // M3: (k1, h0)
+            if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CGPT_SLOT_END
+#undef CGPT_RD_A
+#undef CGPT_RD_W
+#undef CGPT_MMQ
+        }
+        if (!late) { CGPT_SLOT_END }                   // the early half waits one slot for its partners' last M
+
+        const int etm = tm, etn = tn;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
+        if (t + (int)gridDim.x < ntiles) { set_tile(t + gridDim.x); request_all(c & 1, 0); }
+        gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g,
+                                      (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2));
+    }
+#undef CGPT_FENCE
+#undef CGPT_SLOT_END
+}
+
+template <int EPI>
+hipError_t launch_v5(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm5_f16_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = tiles < num_cus ? tiles : num_cus;
+    hipLaunchKernelGGL((gemm5_f16_kernel<EPI>), dim3(grid), dim3(512), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_v5_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
+    switch (epilogue) {
+        case EPI_F16: return launch_v5<EPI_F16>(p, stream);
+        case EPI_F16_GELU: return launch_v5<EPI_F16_GELU>(p, stream);
+        case EPI_F32: return launch_v5<EPI_F32>(p, stream);
+        case EPI_RESID: return launch_v5<EPI_RESID>(p, stream);
+        case EPI_PATCH: return launch_v5<EPI_PATCH>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 }  // namespace
 
 int g_gemm_kernel = 0;
@@ -922,6 +1114,7 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     if (force == 4) return launch_v3_epi<4>(epilogue, p, stream);
     if (force == 5) return launch_v3_epi<2>(epilogue, p, stream);
     if (force == 6) return launch_v4_epi<4>(epilogue, p, stream);
+    if (force == 8) return launch_v5_epi(epilogue, p, stream);
     if (force == 7) return launch_v4_epi<5>(epilogue, p, stream);
     if (force == 0 && p.M >= 1024) {
         // measured on MI355X (profiles/r01/gemm_variants.txt): the 256x256 direct-to-LDS tile wins on every ViT / Q-Former
