@@ -205,3 +205,59 @@ def test_vitg_matches_oracle_on_two_samples(vitg):
     e_vit = rel_err(vit_gpu, ref["vit_out"])
     e_log = rel_err(logits, ref["logits"])
     assert e_vit <= 2e-2 and e_log <= 2e-2, (e_vit, e_log)
+
+
+def test_predict_and_n1000_sharded_125_per_gpu_match_single_pass():
+    """BASELINE config 4 shape on the tiny model: N=1000 split 125 per rank over 8 ranks == one pass; Smooth.predict
+    decisions on the GPU counts == the oracle's (smoothing.py:58-79)."""
+    K = 10
+    clf, p16, params, cfg = tiny_pair(mo.MODE_VIT_HEAD, num_classes=K, max_batch=125)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    full = clf.sample_counts(x0, 0, 1000, 125, 0.25, 9)
+    parts = torch.zeros_like(full)
+    for r in range(8):
+        lo, hi = cg.shard_range(1000, r, 8)
+        assert hi - lo == 125
+        clf.sample_counts(x0, lo, hi - lo, 125, 0.25, 9, counts=parts)
+    assert torch.equal(full, parts) and int(full.sum()) == 1000
+    s = cg.Smooth(clf, K, 0.25, seed=9)
+    for alpha in (0.001, 0.05, 0.5):
+        s.reset()
+        got = s.predict(x0, 1000, alpha, 125)
+        assert got == so.predict_from_counts(full.cpu().numpy(), alpha)
+        assert isinstance(got, int)
+    # certify at N=1000 through the fused pass == oracle statistics on the same counts
+    s.reset()
+    lab, rad = s.certify(x0, 1000, 1000, 0.001, 125)
+    est = clf.sample_counts(x0, 1000, 1000, 125, 0.25, 9)
+    olab, orad = so.certify_from_counts(full.cpu().numpy(), est.cpu().numpy(), 1000, 0.001, 0.25)
+    assert lab == olab and abs(rad - orad) <= 1e-9
+
+
+def test_edge_cases_and_errors():
+    import ctypes as C
+    K = 10
+    clf, p16, params, cfg = tiny_pair(mo.MODE_VIT_HEAD, num_classes=K, max_batch=4)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    assert int(clf.sample_counts(x0, 0, 0, 4, 0.5, 1).sum()) == 0                      # empty range
+    one = clf.sample_counts(x0, 7, 1, 4, 0.5, 1)                                       # single sample
+    assert int(one.sum()) == 1
+    a = clf.sample_counts(x0, 0, 11, 1, 0.5, 1)                                        # batch_size 1, ragged count
+    b = clf.sample_counts(x0, 0, 11, 4, 0.5, 1)
+    assert torch.equal(a, b)
+    big = clf.sample_counts(x0, 0, 11, 1000, 0.5, 1)                                   # batch_size > max_batch is clamped by the binding
+    assert torch.equal(big, b)
+    counts = torch.zeros(K, dtype=torch.int64, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert clf._L.cgpt_sample_counts(clf._h, C.c_void_p(x0.data_ptr()), 0, 4, 5, 0.5, 1, C.c_void_p(counts.data_ptr()), st) == 1   # > max_batch
+    assert clf._L.cgpt_sample_counts(clf._h, C.c_void_p(x0.data_ptr()), 0, -1, 4, 0.5, 1, C.c_void_p(counts.data_ptr()), st) == 1  # negative count
+    assert clf._L.cgpt_sample_counts(clf._h, None, 0, 4, 4, 0.5, 1, C.c_void_p(counts.data_ptr()), st) == 1                         # null image
+    with pytest.raises(ValueError):
+        clf.sample_counts(torch.zeros(3, 8, 8, device=DEV), 0, 1, 1, 0.5, 1)             # wrong image shape
+    with pytest.raises(TypeError):
+        clf.sample_counts(x0.cpu(), 0, 1, 1, 0.5, 1)                                     # host tensor: no CPU path
+    # sigma = 0: every sample sees the clean image -> unanimous vote
+    z = clf.sample_counts(x0, 0, 9, 4, 0.0, 1)
+    assert int(z.max()) == 9
+    clean = clf(x0[None])
+    assert int(z.argmax()) == int(clean.argmax())
