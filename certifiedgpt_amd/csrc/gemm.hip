@@ -78,13 +78,13 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int& tm,
 
 // Same map for a VIRTUAL block id t in [0, nwg) (persistent kernel: physical block b walks t = b, b + grid, ...; with a grid
 // that is a multiple of 8, t and b sit on the same XCD).
-__device__ __forceinline__ void tile_of_virtual_block(int vb, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void tile_of_virtual_block(int vb, int nwg, int tiles_m, int tiles_n, int& tm, int& tn, int group_m = GROUP_M) {
     const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int per_group = GROUP_M * tiles_n;
+    const int per_group = group_m * tiles_n;
     const int grp = t / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int first_m = grp * group_m;
+    const int gsz = min(tiles_m - first_m, group_m);
     const int in_grp = t - grp * per_group;
     tm = first_m + in_grp % gsz;
     tn = in_grp / gsz;
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
     const half_t* b_src[B_INSTR];
     int tm = 0, tn = 0;
     auto set_tile = [&](int t) {
-        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn);
+        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn, p.group_m);
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             const int r = wave * (BM2 / 8) + i * 8 + lr;
@@ -1097,11 +1097,13 @@ hipError_t launch_v5_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
 
 int g_gemm_kernel = 0;
 int g_gemm_ablate = 0;
+int g_gemm_group_m = 4;   // measured: 4 ~ 8 > 2 > 16 (profiles/r01/gemm_variants.txt)
 unsigned long long* g_gemm_dbg = nullptr;
 
 hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.ablate = g_gemm_ablate;
+    p.group_m = g_gemm_group_m;
     p.dbg = g_gemm_dbg;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
         return hipErrorInvalidValue;

@@ -27,10 +27,12 @@ struct GemmParams {
     int M, N, K;
     int patches;                  // EPI_PATCH: P (patches per image)
     unsigned long long* dbg = nullptr;   // diagnostic builds only (-DCGPT_STAMPS): per-wave cycle sums
+    int group_m = 8;              // tile-rows per group in the block->tile map (speed only)
     int ablate = 0;               // measurement only: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
 extern int g_gemm_ablate;
+extern int g_gemm_group_m;
 extern unsigned long long* g_gemm_dbg;
 extern int g_gemm_kernel;   // kernel override for A/B measurements: 0 auto, 1 v1, 2 v2<256>, 3 v2<128>
 

@@ -629,7 +629,8 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
         g_gemm_kernel = value;
         return CGPT_OK;
     }
-    if (k == "gemm_ablate") { g_gemm_ablate = value; return CGPT_OK; }   // measurement only (wrong results)
+    if (k == "gemm_ablate") { g_gemm_ablate = value; return CGPT_OK; }
+    if (k == "gemm_group_m") { if (value < 1) return cgpt_fail(CGPT_ERR_INVALID, "gemm_group_m >= 1"); g_gemm_group_m = value; return CGPT_OK; }   // measurement only (wrong results)
     return cgpt_fail(CGPT_ERR_NOT_FOUND, "cgpt_set_option: unknown option '" + k + "'");
 }
 

@@ -58,3 +58,17 @@ def test_duplicate_registration_rejected():
         @registry.register_agent("image_text_certify")
         class Again(BaseAgent):
             pass
+
+
+def test_label_adapter_matches_reference_normaliser_goldens():
+    import os
+    from conftest import GOLDEN
+    from certifiedgpt_amd.agents.label_adapter import normalize_answer, AnswerLabelMap
+    cases = json.load(open(os.path.join(GOLDEN, "label_adapter_golden.json")))["cases"]
+    assert len(cases) >= 30
+    for c in cases:
+        assert normalize_answer(c["answer"]) == c["normalized"], c
+    m = AnswerLabelMap(4)
+    assert [m(t) for t in ("Yes", "yes.", "No", "a cat", "the cat", "dog", "bird")] == [0, 0, 1, 2, 2, 3, 3]   # cap -> "other"
+    logits = m.one_hot_logits(["yes", "no"])
+    assert logits.shape == (2, 4) and logits[0, 0] == 1 and logits[1, 1] == 1
