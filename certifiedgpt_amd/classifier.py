@@ -84,6 +84,8 @@ class HipClassifier:
             if k not in names:
                 continue
             a = np.ascontiguousarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
+            if k == "visual_encoder.pos_embed" and a.size != self._L.cgpt_weight_numel(self._h, k.encode()):
+                a = np.ascontiguousarray(interpolate_pos_embed(a, self.tokens - 1), dtype=np.float32)
             _lib.check(self._L.cgpt_load_weight(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size))
         return missing, unexpected
 
@@ -167,6 +169,24 @@ class HipClassifier:
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         _lib.check(self._L.cgpt_profile_read(self._h, kind, C.byref(ms), C.byref(fl), C.byref(n)))
         return ms.value, fl.value, n.value
+
+
+def interpolate_pos_embed(pos_embed, num_patches):
+    """Resize a checkpoint's position embedding [1, 1+P0, D] to this model's grid (reference interpolate_pos_embed,
+    eva_vit.py:383-404: the class token is kept, the patch tokens are resized with bicubic interpolation,
+    align_corners=False).  Host-side, at load time only."""
+    pe = torch.as_tensor(np.asarray(pos_embed), dtype=torch.float32)
+    pe = pe.reshape(1, -1, pe.shape[-1])
+    D = pe.shape[-1]
+    extra = 1
+    orig = int((pe.shape[-2] - extra) ** 0.5)
+    new = int(num_patches ** 0.5)
+    if orig == new:
+        return pe.numpy()
+    tok = pe[:, extra:].reshape(-1, orig, orig, D).permute(0, 3, 1, 2)
+    tok = torch.nn.functional.interpolate(tok, size=(new, new), mode="bicubic", align_corners=False)
+    tok = tok.permute(0, 2, 3, 1).flatten(1, 2)
+    return torch.cat((pe[:, :extra], tok), dim=1).numpy()
 
 
 def noise_batch(x, first_sample, num, sigma, seed):

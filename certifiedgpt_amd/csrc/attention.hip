@@ -286,6 +286,224 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------- streaming variant
+// Tk > 288 (448^2 images: T = 1025, the reference's own image size, minigpt4.py:32; eva_vit.py:383-404): K and V no longer
+// fit in LDS, so a workgroup owns 128 queries (one 16-query tile per wave) of one (sample, head) and streams the keys
+// through LDS in chunks of 288 with an online softmax.  With the transposed product O^T = V^T P^T the query sits on the
+// lane, so the running maximum m, the rescale factor alpha = 2^((m_old - m_new) scale log2e) and -- through the ones
+// column of V -- the running denominator are all lane-local: a rescale is one multiply per accumulator register.
+template <int HD, int DPAD>
+__global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NKT = 18, NT = 512;
+    constexpr int KROW = AttnLayout<DPAD>::KROW, VSTR = AttnLayout<DPAD>::VSTR;
+    constexpr int TKP = NKT * 16;
+    constexpr int CH = DPAD / 8, NDS = DPAD / 32, NDT = DPAD / 16;
+    constexpr int NV = (TKP * CH + NT - 1) / NT;
+    half_t* Ks = reinterpret_cast<half_t*>(smem_raw);
+    half_t* Vs = Ks + TKP * KROW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r15 = lane & 15, g = lane >> 4;
+    const int nqb = (p.Tq + 127) / 128;
+    const int nitems = p.heads * p.B * nqb;
+    const int nchunks = (p.Tk + TKP - 1) / TKP;
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int qb = item % nqb, h = (item / nqb) % p.heads, b = item / (nqb * p.heads);
+        const half_t* Kg = p.K + (int64_t)b * p.kv_batch_stride + h * HD;
+        const half_t* Vg = p.V + (int64_t)b * p.kv_batch_stride + h * HD;
+        const half_t* Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
+        half_t* Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
+        const int qt = qb * 8 + wave;
+        const bool have = qt * 16 < p.Tq;
+
+        f16x8 qf[NDS];
+        {
+            const int qrow = min(qt * 16 + r15, p.Tq - 1);
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                const int d = min(ds * 32 + g * 8, HD - 8);
+                const f16x8 v = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
+                qf[ds] = (ds * 32 + g * 8 < HD) ? v : zero8;
+            }
+        }
+        f32x4 o[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_run = -1e30f, l_run = 0.f;
+
+        for (int c = 0; c < nchunks; ++c) {
+            const int key0 = c * TKP;
+            const int nk = min(TKP, p.Tk - key0);
+            __syncthreads();                               // every wave is done with the previous chunk's images
+            {
+                f16x8 kreg[NV], vreg[NV];
+#pragma unroll
+                for (int it = 0; it < NV; ++it) {
+                    const int idx = tid + it * NT;
+                    const int row = key0 + min(idx / CH, nk - 1), ch = min(idx % CH, HD / 8 - 1);
+                    kreg[it] = *reinterpret_cast<const f16x8*>(Kg + (int64_t)row * p.ldk + ch * 8);
+                    vreg[it] = *reinterpret_cast<const f16x8*>(Vg + (int64_t)row * p.ldv + ch * 8);
+                }
+#pragma unroll
+                for (int it = 0; it < NV; ++it) {
+                    const int idx = tid + it * NT;
+                    const int row = idx / CH, ch = idx - row * CH;
+                    const bool valid = row < nk && ch * 8 < HD;
+                    f16x8 vv = valid ? vreg[it] : zero8;
+                    if (DPAD > HD && ch * 8 == HD) vv = f16x8{(half_t)1.0f, 0, 0, 0, 0, 0, 0, 0};
+                    if (idx < TKP * CH) {
+                        *reinterpret_cast<f16x8*>(Ks + row * KROW + k_chunk_pos<DPAD>(row, ch) * 8) = valid ? kreg[it] : zero8;
+                        *reinterpret_cast<f16x8*>(Vs + row * VSTR + ch * 8) = vv;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!have) continue;
+
+            // ---- S^T for this chunk
+            f32x4 s[NKT];
+            {
+                constexpr int KD = 2;
+                f16x8 kring[KD + 1][NDS];
+                auto kaddr = [&](int kt, int ds) {
+                    const int row = kt * 16 + r15;
+                    return Ks + row * KROW + k_chunk_pos<DPAD>(row, ds * 4 + g) * 8;
+                };
+#pragma unroll
+                for (int kt = 0; kt < KD; ++kt)
+#pragma unroll
+                    for (int ds = 0; ds < NDS; ++ds) kring[kt % (KD + 1)][ds] = *reinterpret_cast<const f16x8*>(kaddr(kt, ds));
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    if (kt + KD < NKT) {
+#pragma unroll
+                        for (int ds = 0; ds < NDS; ++ds)
+                            kring[(kt + KD) % (KD + 1)][ds] = *reinterpret_cast<const f16x8*>(kaddr(kt + KD, ds));
+                    }
+                    CGPT_FENCE
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ds = 0; ds < NDS; ++ds)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kring[kt % (KD + 1)][ds], qf[ds], acc, 0, 0, 0);
+                    s[kt] = acc;
+                    CGPT_FENCE
+                }
+            }
+            // ---- online softmax (everything per query = per lane group r15)
+            float mx = -1e30f;
+            const int klim = nk - 4 * g;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                if (kt * 16 + 16 > nk) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + r >= klim) s[kt][r] = -1e30f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);    // first chunk: 2^(-huge) = 0, O is 0 anyway
+            m_run = m_new;
+            const float mxs = m_new * sl2;
+            float sm = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, -mxs));
+                    s[kt][r] = e;
+                    if constexpr (DPAD == HD) sm += e;
+                }
+            if constexpr (DPAD == HD) {
+                sm += __shfl_xor(sm, 16);
+                sm += __shfl_xor(sm, 32);
+                l_run = l_run * alpha + sm;
+            }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+            // ---- O^T += V^T P^T
+            {
+                const half_t* vbase = Vs + (4 * g + (r15 >> 2)) * VSTR + 4 * (r15 & 3);
+                constexpr int NU = NKT / 2;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    f16x4 vr[NDT][2];
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        const half_t* a1 = vbase + (32 * u) * VSTR + dt * 16;
+                        vr[dt][0] = lds_read_tr16(a1);
+                        vr[dt][1] = lds_read_tr16(a1 + 16 * VSTR);
+                    }
+                    f16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pf[j] = (half_t)s[2 * u][j];
+                        pf[4 + j] = (half_t)s[2 * u + 1][j];
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        const f16x8 vf = {vr[dt][0][0], vr[dt][0][1], vr[dt][0][2], vr[dt][0][3],
+                                          vr[dt][1][0], vr[dt][1][1], vr[dt][1][2], vr[dt][1][3]};
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (have) {
+            float den = l_run;
+            if constexpr (DPAD > HD) {
+                constexpr int DT = HD / 16, GG = (HD % 16) / 4, RR = (HD % 16) % 4;
+                den = __shfl(o[DT][RR], 16 * GG + r15);
+            }
+            const float inv = 1.0f / den;
+            const int q = qt * 16 + r15;
+            if (q < p.Tq) {
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const int d0 = dt * 16 + 4 * g;
+                    if (d0 < HD) {
+                        const f16x4 hv = {(half_t)(o[dt][0] * inv), (half_t)(o[dt][1] * inv), (half_t)(o[dt][2] * inv),
+                                          (half_t)(o[dt][3] * inv)};
+                        *reinterpret_cast<f16x4*>(Ob + (int64_t)q * p.ldo + d0) = hv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int HD, int DPAD>
+hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
+    constexpr int lds_bytes = 18 * 16 * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_stream_kernel<HD, DPAD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int items = p.heads * p.B * ((p.Tq + 127) / 128);
+    const int grid = items < num_cus ? items : num_cus;
+    hipLaunchKernelGGL((attention_stream_kernel<HD, DPAD>), dim3(grid), dim3(512), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
 #undef CGPT_FENCE
 
 template <int HD, int DPAD, int NKT, int NT>
@@ -318,7 +536,11 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.heads <= 0 || p.Tq <= 0 || p.Tk <= 0) return hipErrorInvalidValue;
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8)) return hipErrorInvalidValue;   // 16-byte row alignment
     const bool small = p.Tk <= 32;
-    if (p.Tk > 288) return hipErrorInvalidValue;   // whole-K/V-in-LDS design: T <= 288 (224^2 images; 448^2 is "next")
+    if (p.Tk > 288) {                               // K/V streamed through LDS in 288-key chunks (448^2 images)
+        if (p.head_dim == 88) return launch_stream<88, 96>(p, stream);
+        if (p.head_dim == 64) return launch_stream<64, 64>(p, stream);
+        return hipErrorInvalidValue;
+    }
     if (p.head_dim == 88) return small ? launch_one<88, 96, 2, 128>(p, stream) : launch_one<88, 96, 18, 512>(p, stream);
     if (p.head_dim == 64) return small ? launch_one<64, 64, 2, 128>(p, stream) : launch_one<64, 64, 18, 512>(p, stream);
     return hipErrorInvalidValue;

@@ -414,7 +414,7 @@ cgpt_status cgpt_create(const cgpt_config* cfg, cgpt_handle* out) {
     const int hd = c.vit_dim / c.vit_heads;
     if (hd != 88 && hd != 64) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: ViT head_dim must be 88 or 64");
     const int T = (c.img_size / c.patch_size) * (c.img_size / c.patch_size) + 1;
-    if (T > 288) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: more than 288 tokens (448^2 images) is not supported yet");
+    if (T > 4097) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_create: more than 4097 tokens per image");
     if (c.mode == CGPT_MODE_ENCODE_IMG) {
         if (c.qf_layers < 1 || c.qf_dim < 8 || c.qf_heads < 1 || c.qf_dim % c.qf_heads || c.qf_dim / c.qf_heads != 64 ||
             c.qf_ffn < 8 || (c.qf_ffn & 7) || c.qf_queries < 1 || c.qf_queries > 32 || c.qf_xattn_freq < 1 || c.proj_dim < 8 ||

@@ -182,7 +182,8 @@ cgpt_status cgpt_linear_f16(const void* A_dev, int64_t lda, const void* W_dev, i
                             void* out_dev, int64_t ldo, const float* aux_dev, int64_t ldaux, int64_t M, int64_t N, int64_t K,
                             int32_t epilogue, void* stream);
 /* softmax(scale * Q K^T) V per (batch, head): Q [B,Tq,ldq] K,V [B,Tk,ldkv] fp16 with head h at column h*head_dim;
- * O [B,Tq,ldo] fp16.  head_dim in {64, 88}.  (eva_vit.py:133-150; Qformer.py:244-264 with zero masks) */
+ * O [B,Tq,ldo] fp16.  head_dim in {64, 88}.  (eva_vit.py:133-150; Qformer.py:244-264 with zero masks)
+ * Tk <= 288: K/V of a head resident in LDS; Tk > 288 (448^2 images): K/V streamed in 288-key chunks, online softmax. */
 cgpt_status cgpt_attention_f16(const void* Q_dev, int64_t ldq, const void* K_dev, const void* V_dev, int64_t ldkv,
                                void* O_dev, int64_t ldo, int32_t B, int32_t heads, int32_t head_dim,
                                int32_t Tq, int32_t Tk, float scale, void* stream);

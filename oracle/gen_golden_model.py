@@ -142,8 +142,15 @@ def main():
         ref_q = out.last_hidden_state if hasattr(out, "last_hidden_state") else out[0]
         ref_llama = llama_proj(ref_q)                                # minigpt4.py:141
 
+    # ---------------- reference interpolate_pos_embed (eva_vit.py:383-404): a 2x2-grid checkpoint resized to this 4x4 model
+    ck_pos = philox.normal_stream(77, 0, (1 + 4) * cfg.vit_dim).reshape(1, 5, cfg.vit_dim)
+    ck = {"pos_embed": torch.from_numpy(ck_pos.copy())}
+    eva.interpolate_pos_embed(vit, ck)
+    ref_interp = ck["pos_embed"].numpy()
+    assert ref_interp.shape == (1, cfg.tokens, cfg.vit_dim)
+
     path = os.path.join(ROOT, "tests", "golden", "model_golden.npz")
-    np.savez_compressed(path, seed=np.int64(seed), x=x.numpy(), vit_out=ref_vit.numpy(),
+    np.savez_compressed(path, seed=np.int64(seed), x=x.numpy(), vit_out=ref_vit.numpy(), pos_ck=ck_pos, pos_interp=ref_interp,
                         ln_vision=image_embeds.numpy(), qformer=ref_q.numpy(), llama=ref_llama.numpy())
     print("wrote", path, os.path.getsize(path), "bytes; vit_out", tuple(ref_vit.shape), "qformer", tuple(ref_q.shape))
 

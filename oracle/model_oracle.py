@@ -229,6 +229,23 @@ def forward_all(p, x, cfg: Config):
         return out
 
 
+def interpolate_pos_embed(pos_embed_checkpoint, num_patches):
+    """eva_vit.py:383-404 restated: keep the extra (class) token, bicubic-resize the square grid of patch tokens."""
+    pe = torch.as_tensor(pos_embed_checkpoint, dtype=torch.float32)
+    embedding_size = pe.shape[-1]
+    num_extra_tokens = 1                                               # model.pos_embed.shape[-2] - num_patches (:388)
+    orig_size = int((pe.shape[-2] - num_extra_tokens) ** 0.5)          # :390
+    new_size = int(num_patches ** 0.5)                                 # :392
+    if orig_size == new_size:
+        return pe
+    extra_tokens = pe[:, :num_extra_tokens]
+    pos_tokens = pe[:, num_extra_tokens:]
+    pos_tokens = pos_tokens.reshape(-1, orig_size, orig_size, embedding_size).permute(0, 3, 1, 2)
+    pos_tokens = F.interpolate(pos_tokens, size=(new_size, new_size), mode="bicubic", align_corners=False)   # :400-401
+    pos_tokens = pos_tokens.permute(0, 2, 3, 1).flatten(1, 2)
+    return torch.cat((extra_tokens, pos_tokens), dim=1)                # :403
+
+
 def make_classifier(p, cfg: Config):
     """base_classifier([B,C,H,W] float32) -> logits [B,num_classes] numpy, for SmoothOracle."""
     def f(batch):

@@ -119,7 +119,10 @@ def attn_ref(q, k, v, heads, hd, scale):
 
 @pytest.mark.parametrize("B,heads,hd,Tq,Tk", [(3, 2, 88, 257, 257), (2, 16, 88, 257, 257), (2, 2, 88, 17, 17),
                                                (3, 12, 64, 32, 257), (2, 12, 64, 32, 32), (2, 2, 64, 8, 17),
-                                               (1, 2, 64, 8, 8), (1, 1, 88, 1, 1)])
+                                               (1, 2, 64, 8, 8), (1, 1, 88, 1, 1),
+                                               # Tk > 288: K/V streamed through LDS in 288-key chunks (448^2 images, T = 1025)
+                                               (2, 2, 88, 401, 401), (1, 16, 88, 1025, 1025), (2, 12, 64, 32, 1025),
+                                               (1, 2, 88, 130, 300), (1, 2, 64, 289, 289), (1, 1, 88, 1, 577)])
 def test_attention_matches_fp32_reference(B, heads, hd, Tq, Tk):
     L = cg.lib()
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + Tq + Tk)

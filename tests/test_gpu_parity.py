@@ -261,3 +261,31 @@ def test_edge_cases_and_errors():
     assert int(z.max()) == 9
     clean = clf(x0[None])
     assert int(z.argmax()) == int(clean.argmax())
+
+
+def test_larger_image_streaming_attention_and_pos_embed_interpolation():
+    """Section 8(f) rank 3: images whose token count exceeds the in-LDS attention limit (280x280 -> T = 401 here;
+    448x448 -> 1025 in the reference, minigpt4.py:32) and a checkpoint pos_embed from a smaller grid
+    (interpolate_pos_embed, eva_vit.py:383-404)."""
+    import dataclasses
+    cfg = dataclasses.replace(mo.tiny_config(mode=mo.MODE_ENCODE_IMG, num_classes=10), img_size=280)
+    assert cfg.tokens == 401
+    params = mo.init_params(cfg, 5)
+    # pretend the checkpoint was trained at 56x56 (4x4 grid): hand the small pos_embed to the loader
+    small = mo.init_params(mo.tiny_config(mode=mo.MODE_ENCODE_IMG, num_classes=10), 5)["visual_encoder.pos_embed"]
+    state = dict(params)
+    state["visual_encoder.pos_embed"] = small
+    clf = make_classifier(cfg, max_batch=3)
+    clf.load_state_dict(state)
+    params["visual_encoder.pos_embed"] = mo.interpolate_pos_embed(small, cfg.tokens - 1)
+    assert np.abs(clf.get_weight("visual_encoder.pos_embed") - params["visual_encoder.pos_embed"].numpy().reshape(-1)).max() <= 1e-6
+    p16 = mo.round_fp16_weights(params)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    noisy = cg.noise_batch(x0, 0, 3, 0.5, 42)
+    logits = clf(noisy)
+    ref = mo.forward_all(p16, noisy.cpu(), cfg)
+    for what in ("vit_out", "ln_vision", "qformer", "llama"):
+        e = rel_err(clf.activation(what, 3), ref[what])
+        assert e <= 1e-2, (what, e)
+    assert rel_err(logits, ref["logits"]) <= 1e-2
+    assert torch.equal(clf.forward_logits(x0, 0, 3, 0.5, 42), logits)

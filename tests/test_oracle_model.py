@@ -44,3 +44,13 @@ def test_param_table_matches_reference_sizes():
     assert vit == 985_894_528
     qf = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("Qformer."))
     assert abs(qf - 105.14e6) < 0.01e6
+
+
+def test_interpolate_pos_embed_matches_reference_function():
+    g = np.load(os.path.join(GOLDEN, "model_golden.npz"))
+    got = mo.interpolate_pos_embed(torch.from_numpy(g["pos_ck"]), 16).numpy()
+    assert np.abs(got - g["pos_interp"]).max() <= 1e-6
+    import certifiedgpt_amd as cg
+    got2 = cg.interpolate_pos_embed(g["pos_ck"], 16)
+    assert np.abs(got2 - g["pos_interp"]).max() <= 1e-6
+    assert np.array_equal(cg.interpolate_pos_embed(g["pos_interp"], 16), g["pos_interp"])     # same grid: untouched
