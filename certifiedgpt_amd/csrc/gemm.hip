@@ -911,7 +911,7 @@ hipError_t launch_v4_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
 // The reads of a stage end in L2, two phases before the K-tile boundary; the stage is re-requested one K-tile later.
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm5_f16_kernel(GemmParams p) {
-    constexpr int NQ = 4;
+    // 4 phases per K-tile
     constexpr int BM2 = 256, BN_ = 256, WN = 4, WM = 2;
     constexpr int TM = 8, TN = 4, HM = 4;
     constexpr int A_ELEMS = BM2 * BK, B_ELEMS = BN_ * BK, STAGE = A_ELEMS + B_ELEMS;
