@@ -53,6 +53,8 @@ SIGNATURES = {
     "cgpt_vote": (_I32, [_P, _I64, _I32, _P, _P]),
     "cgpt_certify_from_counts": (_I32, [_P, _P, _I32, _I64, _D, _D, C.POINTER(_I32), C.POINTER(_D)]),
     "cgpt_predict_from_counts": (_I32, [_P, _I32, _D, C.POINTER(_I32)]),
+    "cgpt_certify_device": (_I32, [_P, _P, _I32, _I64, _D, _D, _P, _P]),
+    "cgpt_predict_device": (_I32, [_P, _I32, _D, _P, _P]),
     "cgpt_lower_confidence_bound": (_D, [_I64, _I64, _D]),
     "cgpt_binom_test": (_D, [_I64, _I64, _D]),
     "cgpt_norm_ppf": (_D, [_D]),

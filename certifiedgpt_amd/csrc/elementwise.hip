@@ -6,6 +6,7 @@
 // minigpt4.py:132 (query_tokens.expand), Qformer.py:106 (embeddings LayerNorm).
 #include "kernels.h"
 #include "philox.h"
+#include "stats.h"
 
 namespace cgpt {
 
@@ -260,6 +261,53 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ log
     if (lane == 0) atomicAdd((s < na ? counts : counts_b) + bi, 1ull);   // rows >= na belong to the second range
 }
 
+
+// ------------------------------------------------------------------- device-side finalisation of certify / predict
+// One wave.  Smooth.certify lines 46-56 (smoothing.py): cAHat = first maximal index of the selection histogram
+// (64 lanes scan K/64 classes each, then a 6-step xor-shuffle butterfly keeps (larger count, then smaller index)),
+// nA = estimation[cAHat], Clopper-Pearson lower bound and sigma * Phi^-1 in float64 by lane 0 (stats.h, the same
+// code the host path runs).  Smooth.predict lines 73-79: top-2 counts by two butterflies, two-sided binomial test.
+// out[0] = label (as double), out[1] = radius (certify) or p-value (predict).
+__global__ __launch_bounds__(64) void finalize_kernel(const long long* __restrict__ csel, const long long* __restrict__ cest,
+                                                      int K, long long n, double alpha, double sigma, int predict,
+                                                      double* __restrict__ out) {
+    const int lane = threadIdx.x;
+    auto wave_argmax = [&](const long long* c, int skip) {
+        long long best = -1;
+        int bi = 0x7fffffff;
+        for (int k = lane; k < K; k += 64) {
+            if (k == skip) continue;
+            const long long v = c[k];
+            if (v > best) { best = v; bi = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        return bi;
+    };
+    if (!predict) {
+        const int cAHat = wave_argmax(csel, -1);
+        if (lane == 0) {
+            const long long nA = cest[cAHat];
+            const double pABar = cgpt_stats::cp_lower_bound(nA, n, alpha);
+            if (pABar < 0.5) { out[0] = -1.0; out[1] = 0.0; }
+            else { out[0] = (double)cAHat; out[1] = sigma * cgpt_stats::norm_ppf(pABar); }
+        }
+    } else {
+        const int i1 = wave_argmax(cest, -1);
+        const int i2 = wave_argmax(cest, i1);
+        if (lane == 0) {
+            const long long c1 = cest[i1], c2 = cest[i2];
+            const double pv = cgpt_stats::binom_test_two_sided(c1, c1 + c2, 0.5);
+            out[0] = pv > alpha ? -1.0 : (double)i1;
+            out[1] = pv;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------- fills and casts
 __global__ void fill_normal_kernel(void* dst, int is_f16, int64_t rows, int64_t cols, int64_t ld, float mean,
                                    float stdv, uint64_t seed, uint64_t tensor_id) {
@@ -395,6 +443,13 @@ hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int6
     if (num <= 0) return hipSuccess;
     hipLaunchKernelGGL(vote_kernel, dim3((unsigned)((num + 3) / 4)), dim3(256), 0, stream, logits, ld, num, K,
                        reinterpret_cast<unsigned long long*>(counts), na, reinterpret_cast<unsigned long long*>(counts_b));
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const int64_t* csel, const int64_t* cest, int K, int64_t n, double alpha, double sigma, int predict,
+                           double* out, hipStream_t stream) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const long long*>(csel),
+                       reinterpret_cast<const long long*>(cest), K, (long long)n, alpha, sigma, predict, out);
     return hipGetLastError();
 }
 

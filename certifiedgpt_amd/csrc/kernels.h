@@ -84,6 +84,10 @@ hipError_t launch_mean_rows(const float* src, int64_t lds, int rows, int D, int 
 // Rows b < na vote into counts, rows b >= na into counts_b.
 hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int64_t* counts, int64_t na, int64_t* counts_b,
                        hipStream_t stream);
+// Smooth.certify lines 46-56 (predict = 0) or Smooth.predict lines 73-79 (predict = 1) on device histograms; one wave.
+// out[0] = label, out[1] = radius | p-value (float64).
+hipError_t launch_finalize(const int64_t* csel, const int64_t* cest, int K, int64_t n, double alpha, double sigma, int predict,
+                           double* out, hipStream_t stream);
 // Fill a tensor from the counter-based normal stream: dst = mean + std * z (fp16 or fp32 destination, 2-D with ld).
 hipError_t launch_fill_normal(void* dst, int is_f16, int64_t rows, int64_t cols, int64_t ld, float mean, float std,
                               uint64_t seed, uint64_t tensor_id, hipStream_t stream);

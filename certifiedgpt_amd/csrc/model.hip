@@ -621,6 +621,21 @@ cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes,
     return CGPT_OK;
 }
 
+cgpt_status cgpt_certify_device(const int64_t* counts_selection_dev, const int64_t* counts_estimation_dev, int32_t num_classes,
+                                int64_t n, double alpha, double sigma, double* out2_dev, void* stream) {
+    if (!counts_selection_dev || !counts_estimation_dev || !out2_dev || num_classes < 1 || n < 1 || !(alpha > 0.0 && alpha < 1.0))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_certify_device: bad argument");
+    HIPCHK(launch_finalize(counts_selection_dev, counts_estimation_dev, num_classes, n, alpha, sigma, 0, out2_dev, (hipStream_t)stream));
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_predict_device(const int64_t* counts_dev, int32_t num_classes, double alpha, double* out2_dev, void* stream) {
+    if (!counts_dev || !out2_dev || num_classes < 2 || !(alpha > 0.0 && alpha < 1.0))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_predict_device: bad argument (num_classes >= 2 required)");
+    HIPCHK(launch_finalize(counts_dev, counts_dev, num_classes, 1, alpha, 1.0, 1, out2_dev, (hipStream_t)stream));
+    return CGPT_OK;
+}
+
 cgpt_status cgpt_set_option(const char* key, int32_t value) {
     if (!key) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: null key");
     const std::string k(key);

@@ -40,19 +40,24 @@ class Smooth(object):
 
     ABSTAIN = -1  # smoothing.py:17
 
-    def __init__(self, base_classifier, num_classes: int, sigma: float, seed: int = 0, process_group=None):
+    def __init__(self, base_classifier, num_classes: int, sigma: float, seed: int = 0, process_group=None,
+                 device_stats: bool = False):
         """
         :param base_classifier: an engine exposing `sample_counts(x, first_sample, num, batch_size, sigma, seed)`
                (certifiedgpt_amd.HipClassifier), or any callable mapping a [B,C,H,W] CUDA tensor to [B,num_classes]
                logits (e.g. full MiniGPT-4 + label adapter on PyTorch-ROCm): then only noise and vote run in HIP.
         :param num_classes, sigma: as smoothing.py:19-27
         :param seed: key of the counter-based noise stream; sample indices never repeat within one Smooth object
+        :param device_stats: finish certify / predict on the GPU (cgpt_certify_device / cgpt_predict_device: wavefront
+               arg-max, Clopper-Pearson bound, binomial test, Phi^-1 in float64) and copy back 16 bytes instead of the
+               histograms; same float64 code as the host path
         """
         self.base_classifier = base_classifier
         self.num_classes = num_classes
         self.sigma = sigma
         self.seed = int(seed)
         self.process_group = process_group
+        self.device_stats = bool(device_stats)
         self._next_sample = 0
         self._lib = _lib.lib()
 
@@ -64,6 +69,8 @@ class Smooth(object):
             # the n0 selection draws and the n estimation draws are independent (smoothing.py:44,48): run them in the same
             # classifier batches and sum both histograms with ONE all-reduce.  Same sample indices as the two-call path.
             counts_selection, counts_estimation = self._sample_noise_pair(x, n0, n, batch_size)
+            if counts_estimation is None:                  # device_stats: [2, K] int64 on the GPU
+                return self._finalize_device(counts_selection[0], counts_selection[1], n, alpha, predict=False)
         else:
             counts_selection = self._sample_noise(x, n0, batch_size)
             counts_estimation = self._sample_noise(x, n, batch_size)
@@ -81,6 +88,8 @@ class Smooth(object):
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
+        if self.device_stats and counts.is_cuda:
+            return counts, None                            # histograms stay on the device (certify finishes there)
         c = counts.cpu().numpy().astype(int)
         return c[0], c[1]
 
@@ -141,6 +150,18 @@ class Smooth(object):
                                                       len(cs), int(n), float(alpha), float(self.sigma),
                                                       C.byref(label), C.byref(radius)))
         return int(label.value), float(radius.value)
+
+    def _finalize_device(self, csel, cest, n, alpha, predict):
+        out = torch.empty(2, dtype=torch.float64, device=cest.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if predict:
+            _lib.check(self._lib.cgpt_predict_device(C.c_void_p(cest.data_ptr()), cest.numel(), float(alpha),
+                                                     C.c_void_p(out.data_ptr()), st))
+            return int(out[0].item())
+        _lib.check(self._lib.cgpt_certify_device(C.c_void_p(csel.data_ptr()), C.c_void_p(cest.data_ptr()), cest.numel(), int(n),
+                                                 float(alpha), float(self.sigma), C.c_void_p(out.data_ptr()), st))
+        o = out.cpu()
+        return int(o[0].item()), float(o[1].item())
 
     def predict_from_counts(self, counts, alpha: float) -> int:
         c = np.ascontiguousarray(counts, dtype=np.int64)

@@ -152,6 +152,12 @@ cgpt_status cgpt_certify_from_counts(const int64_t* counts_selection, const int6
                                      int32_t* label_out, double* radius_out);
 /* Smooth.predict lines 73-79 given the histogram (smoothing.py:72). */
 cgpt_status cgpt_predict_from_counts(const int64_t* counts, int32_t num_classes, double alpha, int32_t* label_out);
+/* The same two decisions computed ON THE DEVICE from device histograms (no histogram copy, no host sync): one wavefront,
+ * arg-max / top-2 by xor-shuffles, Clopper-Pearson bound, binomial test and Phi^-1 in float64 with the same code as the
+ * host functions.  out2_dev[0] = label (-1 = abstain) as a double, out2_dev[1] = radius (certify) or p-value (predict). */
+cgpt_status cgpt_certify_device(const int64_t* counts_selection_dev, const int64_t* counts_estimation_dev, int32_t num_classes,
+                                int64_t n, double alpha, double sigma, double* out2_dev, void* stream);
+cgpt_status cgpt_predict_device(const int64_t* counts_dev, int32_t num_classes, double alpha, double* out2_dev, void* stream);
 /* Smooth._lower_confidence_bound (smoothing.py:107-117) == statsmodels proportion_confint(NA,N,2*alpha,"beta")[0]. */
 double cgpt_lower_confidence_bound(int64_t NA, int64_t N, double alpha);
 /* scipy.stats.binom_test(x, n, p) two-sided (scipy 1.7 algorithm; call site smoothing.py:76). */

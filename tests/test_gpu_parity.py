@@ -289,3 +289,28 @@ def test_larger_image_streaming_attention_and_pos_embed_interpolation():
         assert e <= 1e-2, (what, e)
     assert rel_err(logits, ref["logits"]) <= 1e-2
     assert torch.equal(clf.forward_logits(x0, 0, 3, 0.5, 42), logits)
+
+
+def test_device_side_statistics_match_reference_goldens(stats_golden):
+    """cgpt_certify_device / cgpt_predict_device (one wavefront: shuffle arg-max, float64 Clopper-Pearson / binomial test /
+    Phi^-1 on the GPU) against the goldens emitted by the reference's own smoothing.py: decisions exact, radius <= 1e-9."""
+    s = cg.Smooth(None, 2, 1.0)
+    worst = 0.0
+    for c in stats_golden["certify"][::2]:
+        s.sigma = c["sigma"]
+        sel = torch.tensor(c["counts_sel"], dtype=torch.int64, device=DEV)
+        est = torch.tensor(c["counts_est"], dtype=torch.int64, device=DEV)
+        lab, rad = s._finalize_device(sel, est, c["n"], c["alpha"], predict=False)
+        assert lab == c["label"], c
+        worst = max(worst, abs(rad - c["radius"]))
+    assert worst <= 1e-9, worst
+    for c in stats_golden["predict"][::2]:
+        cnt = torch.tensor(c["counts"], dtype=torch.int64, device=DEV)
+        assert s._finalize_device(None, cnt, 1, c["alpha"], predict=True) == c["label"], c
+    # end to end: certify with device_stats == certify with host statistics
+    K = 10
+    clf, p16, params, cfg = tiny_pair(mo.MODE_VIT_HEAD, num_classes=K, max_batch=16)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    a = cg.Smooth(clf, K, 0.25, seed=5).certify(x0, 24, 40, 0.05, 16)
+    b = cg.Smooth(clf, K, 0.25, seed=5, device_stats=True).certify(x0, 24, 40, 0.05, 16)
+    assert a[0] == b[0] and abs(a[1] - b[1]) <= 1e-12
