@@ -32,11 +32,11 @@ F_VIT = 520_719_260_160          # FLOP per 224^2 sample, ViT-G GEMMs + attentio
 MFMA_PEAK_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md chip table
 
 
-def synthetic_images(count, device):
+def synthetic_images(count, device, img=224):
     """x = (u - mean)/std, u ~ U[0,1): CLIP-normalised space, where the reference adds its noise
     (processors/base_processor.py:18-20)."""
     g = torch.Generator(device="cpu").manual_seed(1234)
-    u = torch.rand(count, 3, 224, 224, generator=g)
+    u = torch.rand(count, 3, img, img, generator=g)
     mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
     std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
     return ((u - mean) / std).to(device)
@@ -81,7 +81,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # extra data points (NOT the headline line): BASELINE configs[2] without the Vicuna decode, and the reference's own 448^2 size
+    ap.add_argument("--workload", choices=["vit_head", "encode_img"], default="vit_head")
+    ap.add_argument("--img-size", type=int, default=224)
     args = ap.parse_args()
+    headline = args.workload == "vit_head" and args.img_size == 224
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,10 +107,10 @@ def main():
     dev = torch.device("cuda", local)
     # certify runs its n0 + n draws as ONE fused pass; the largest per-rank share of it is one batch
     per_gpu = -(-N0 // world) + -(-N // world)
-    clf = cg.HipClassifier(mode="vit_head", num_classes=NUM_CLASSES, max_batch=per_gpu, device=local)
+    clf = cg.HipClassifier(mode=args.workload, num_classes=NUM_CLASSES, max_batch=per_gpu, device=local, img_size=args.img_size)
     clf.init_synthetic(seed=0)                                         # identical weights on every rank
     smooth = cg.Smooth(clf, NUM_CLASSES, SIGMA, seed=42)
-    images = synthetic_images(args.steps + args.warmup, dev)
+    images = synthetic_images(args.steps + args.warmup, dev, args.img_size)
     torch.cuda.synchronize()
 
     def barrier():
@@ -140,7 +144,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")) as f:
             pm = json.load(f)["fc1"]
-        if world == 1:
+        if world == 1 and headline:
             traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
             traffic_note = ("bytes per launch from profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                             "FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted): read %.0f MB + write %.0f MB vs "
@@ -176,7 +180,14 @@ def main():
                                        "total_ms": all_ms}},
             "results_sample": [[int(l), float(r)] for l, r in results[-3:]],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not headline:
+            T = (args.img_size // 14) ** 2 + 1
+            line["config"]["workload"] = (f"NON-HEADLINE data point: mode={args.workload}, image {args.img_size}x{args.img_size} (T={T}), "
+                                          "random-init weights, Smooth.certify n0=100 n=100 alpha=0.001 sigma=0.5")
+            line.pop("vit_tflops_end_to_end", None)
+            line["roofline"]["traffic"] = None
+            line["roofline"]["flop_per_launch"] = fc1_flops / max(fc1_n, 1)
+        if world == 1 and not args.no_cpu_baseline and headline:
             try:
                 line["cpu_baseline"] = cpu_baseline(clf, images[0])
                 line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
