@@ -1,0 +1,35 @@
+"""Per-rank cost of one certify at the 1/2/4/8-GPU shard sizes, measured on ONE GPU (the driver runs the real N-GPU bench).
+A rank of a G-GPU job runs ceil(100/G)+ceil(100/G) samples as one fused pass; this times exactly that pass (the all-reduce of
+8 KB and the statistics are not included) and prints the implied strong-scaling ceiling.   python tools/shard_bench.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import certifiedgpt_amd as cg
+import bench
+
+def main():
+    dev = torch.device("cuda", 0)
+    x = bench.synthetic_images(1, dev)[0]
+    clf = cg.HipClassifier(mode="vit_head", num_classes=1000, max_batch=200, device=0)
+    clf.init_synthetic(seed=0)
+    base = None
+    for world in (1, 2, 4, 8):
+        na = -(-100 // world); nb = -(-100 // world)
+        for _ in range(2):
+            clf.sample_counts_pair(x, 0, na, 100, nb, na + nb, 0.5, 42)
+        torch.cuda.synchronize()
+        clf.profile_read(0); clf.profile(True)
+        t0 = time.perf_counter(); it = 4 * world
+        for _ in range(it):
+            clf.sample_counts_pair(x, 0, na, 100, nb, na + nb, 0.5, 42)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / it * 1e3
+        clf.profile(False)
+        gms, gfl, gn = clf.profile_read(0)
+        base = base or ms
+        print(f"world {world}: {na + nb:3d} samples/rank  {ms:8.2f} ms/certify-shard  gemms {gms / it:7.2f} ms ({gfl / gms / 1e9:5.0f} TF)"
+              f"  non-gemm {ms - gms / it:6.2f} ms   speed-up ceiling {base / ms:4.2f}x", flush=True)
+    clf.close()
+
+if __name__ == "__main__":
+    main()
