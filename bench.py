@@ -106,7 +106,10 @@ def main():
         _lib.check(cg.lib().cgpt_set_option(b"gemm_kernel", int(os.environ["CGPT_GEMM_KERNEL"])))
     dev = torch.device("cuda", local)
     # certify runs its n0 + n draws as ONE fused pass; the largest per-rank share of it is one batch
-    per_gpu = -(-N0 // world) + -(-N // world)
+    def _share(r):
+        a, b = cg.shard_range(N0, r, world), cg.shard_range(N, r, world, mirrored=True)
+        return (a[1] - a[0]) + (b[1] - b[0])
+    per_gpu = max(_share(r) for r in range(world))                    # 25 at 8 GPUs (13 + 12 on every rank)
     clf = cg.HipClassifier(mode=args.workload, num_classes=NUM_CLASSES, max_batch=per_gpu, device=local, img_size=args.img_size)
     clf.init_synthetic(seed=0)                                         # identical weights on every rank
     smooth = cg.Smooth(clf, NUM_CLASSES, SIGMA, seed=42)

@@ -121,5 +121,12 @@ def test_shard_range_partitions_exactly():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in parts]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+            mparts = [cg.shard_range(num, r, world, mirrored=True) for r in range(world)]
+            assert mparts[0][0] == 0 and mparts[-1][1] == num
+            assert all(mparts[i][1] == mparts[i + 1][0] for i in range(world - 1))
+            assert [hi - lo for lo, hi in mparts] == sizes[::-1]
     # N=100 over 8 GPUs -> 13,13,13,13,12,12,12,12
     assert [hi - lo for lo, hi in (cg.shard_range(100, r, 8) for r in range(8))] == [13] * 4 + [12] * 4
+    # certify pairs the n0 range with the mirrored n range: 25 samples on every rank
+    assert [(a[1] - a[0]) + (b[1] - b[0]) for a, b in ((cg.shard_range(100, r, 8), cg.shard_range(100, r, 8, mirrored=True))
+                                                       for r in range(8))] == [25] * 8

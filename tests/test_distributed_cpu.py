@@ -46,7 +46,8 @@ class PairEngine(IndexedEngine):
 def _single():
     s = cg.Smooth(IndexedEngine(), K, 0.5, seed=11)
     x = torch.zeros(3, 8, 8)
-    return s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist()
+    return (s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist(),
+            s.certify(x, 51, 77, 0.01, 16))               # odd sizes: remainders go to opposite ends of the rank list
 
 
 def _worker(rank, world, port, q, fused=False):
@@ -56,7 +57,8 @@ def _worker(rank, world, port, q, fused=False):
         eng = PairEngine() if fused else IndexedEngine()
         s = cg.Smooth(eng, K, 0.5, seed=11)
         x = torch.zeros(3, 8, 8)
-        out = (s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist())
+        out = (s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist(),
+               s.certify(x, 51, 77, 0.01, 16))
         q.put((rank, out, eng.calls))
     finally:
         dist.destroy_process_group()
@@ -95,7 +97,8 @@ def test_fused_certify_pass_matches_two_pass_single_and_two_ranks():
     expect = _single()
     s = cg.Smooth(PairEngine(), K, 0.5, seed=11)
     x = torch.zeros(3, 8, 8)
-    assert (s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist()) == expect
+    assert (s.certify(x, 100, 100, 0.001, 32), s.predict(x, 125, 0.001, 32), s._sample_noise(x, 10, 4).tolist(),
+            s.certify(x, 51, 77, 0.01, 16)) == expect
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -110,3 +113,7 @@ def test_fused_certify_pass_matches_two_pass_single_and_two_ranks():
         assert out == expect, (rank, out, expect)
     # rank 1: selection shard [50,100), estimation shard [150,200) -- same indices as the unfused path
     assert got[1][2][:2] == [(50, 50, 32), (150, 50, 32)]
+    # odd sizes in the fused pass (cursor at 335): n0 = 51 -> 26 + 25 (remainder to rank 0), n = 77 -> 38 + 39 (mirrored:
+    # remainder to rank 1), i.e. 64 samples on both ranks
+    assert got[0][2][-2:] == [(335, 26, 16), (386, 38, 16)]
+    assert got[1][2][-2:] == [(361, 25, 16), (424, 39, 16)]

@@ -1,5 +1,5 @@
 """Per-rank cost of one certify at the 1/2/4/8-GPU shard sizes, measured on ONE GPU (the driver runs the real N-GPU bench).
-A rank of a G-GPU job runs ceil(100/G)+ceil(100/G) samples as one fused pass; this times exactly that pass (the all-reduce of
+A rank of a G-GPU job runs its shard_range share of the n0 = 100 and n = 100 draws (25 samples at G = 8) as one fused pass; this times exactly that pass (the all-reduce of
 8 KB and the statistics are not included) and prints the implied strong-scaling ceiling.   python tools/shard_bench.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,8 @@ def main():
     clf.init_synthetic(seed=0)
     base = None
     for world in (1, 2, 4, 8):
-        na = -(-100 // world); nb = -(-100 // world)
+        a, b = cg.shard_range(100, 0, world), cg.shard_range(100, 0, world, mirrored=True)
+        na, nb = a[1] - a[0], b[1] - b[0]                      # rank 0's share; every rank has the same total
         for _ in range(2):
             clf.sample_counts_pair(x, 0, na, 100, nb, na + nb, 0.5, 42)
         torch.cuda.synchronize()
