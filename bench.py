@@ -9,6 +9,7 @@ summed with one RCCL all-reduce (strong scaling: the work per certified image is
 estimation draws are independent, so `certify` runs them in the same classifier batches (batch_size = (n0+n)/N per GPU).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    (extra, NON-headline data points: --workload encode_img | rgf, --img-size 448, --n 1000 / --n0 K)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the MLP fc1 GEMM with the GELU epilogue,
@@ -82,10 +83,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # extra data points (NOT the headline line): BASELINE configs[2] without the Vicuna decode, and the reference's own 448^2 size
-    ap.add_argument("--workload", choices=["vit_head", "encode_img"], default="vit_head")
+    ap.add_argument("--workload", choices=["vit_head", "encode_img", "rgf"], default="vit_head")
     ap.add_argument("--img-size", type=int, default=224)
+    ap.add_argument("--n", type=int, default=N)      # BASELINE configs[3]: --n 1000 (sharded 125 / GPU at 8 GPUs)
+    ap.add_argument("--n0", type=int, default=N0)
     args = ap.parse_args()
-    headline = args.workload == "vit_head" and args.img_size == 224
+    headline = args.workload == "vit_head" and args.img_size == 224 and args.n == N and args.n0 == N0
+    n_est, n_sel = args.n, args.n0
+    rgf = args.workload == "rgf"                     # BASELINE configs[4]: 8-step RGF x smoothed predict(N) on ViT-G + head
+    mode = "vit_head" if rgf else args.workload
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,10 +113,10 @@ def main():
     dev = torch.device("cuda", local)
     # certify runs its n0 + n draws as ONE fused pass; the largest per-rank share of it is one batch
     def _share(r):
-        a, b = cg.shard_range(N0, r, world), cg.shard_range(N, r, world, mirrored=True)
+        a, b = cg.shard_range(n_sel, r, world), cg.shard_range(n_est, r, world, mirrored=True)
         return (a[1] - a[0]) + (b[1] - b[0])
-    per_gpu = max(_share(r) for r in range(world))                    # 25 at 8 GPUs (13 + 12 on every rank)
-    clf = cg.HipClassifier(mode=args.workload, num_classes=NUM_CLASSES, max_batch=per_gpu, device=local, img_size=args.img_size)
+    per_gpu = min(max(_share(r) for r in range(world)), 200)          # 25 at 8 GPUs (13 + 12 on every rank)
+    clf = cg.HipClassifier(mode=mode, num_classes=NUM_CLASSES, max_batch=per_gpu, device=local, img_size=args.img_size)
     clf.init_synthetic(seed=0)                                         # identical weights on every rank
     smooth = cg.Smooth(clf, NUM_CLASSES, SIGMA, seed=42)
     images = synthetic_images(args.steps + args.warmup, dev, args.img_size)
@@ -120,9 +126,17 @@ def main():
         if world > 1:
             dist.barrier()
 
+    attack = cg.RGFAttack(smooth, steps=8, num_dirs=1, delta=0.5, lr=0.05, eps=0.25, dir_seed=1234) if rgf else None
+
+    def step(img):
+        if rgf:                                      # attack towards class 1, then the smoothed prediction of the result
+            _, label, hist = attack.attack(img, 1, n_est, ALPHA, per_gpu, targeted=True)
+            return label, hist[-1]
+        return smooth.certify(img, n_sel, n_est, ALPHA, per_gpu)
+
     results = []
     for i in range(args.warmup):
-        results.append(smooth.certify(images[i], N0, N, ALPHA, per_gpu))
+        results.append(step(images[i]))
     torch.cuda.synchronize()
     clf.profile_read(0)
     clf.profile(True)
@@ -130,7 +144,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        results.append(smooth.certify(images[args.warmup + i], N0, N, ALPHA, per_gpu))
+        results.append(step(images[args.warmup + i]))
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -185,8 +199,16 @@ def main():
         }
         if not headline:
             T = (args.img_size // 14) ** 2 + 1
-            line["config"]["workload"] = (f"NON-HEADLINE data point: mode={args.workload}, image {args.img_size}x{args.img_size} (T={T}), "
-                                          "random-init weights, Smooth.certify n0=100 n=100 alpha=0.001 sigma=0.5")
+            what = (f"8-step RGF attack (1 direction per step) + smoothed predict, {attack.forwards_per_image(n_est)} forwards per image"
+                    if rgf else f"Smooth.certify n0={n_sel} n={n_est} alpha=0.001 sigma=0.5")
+            line["config"]["workload"] = (f"NON-HEADLINE data point: mode={mode}, image {args.img_size}x{args.img_size} (T={T}), "
+                                          f"random-init weights, {what}")
+            line["config"].update({"n0": n_sel, "n": n_est})
+            fw = attack.forwards_per_image(n_est) if rgf else n_sel + n_est
+            line["config"]["forwards_per_image"] = fw
+            line["forwards_per_s"] = value * fw
+            if rgf:
+                line["metric"], line["unit"] = "attacked images/sec (8-step RGF, N=%d, sigma=0.5)" % n_est, "attacked images/s"
             line.pop("vit_tflops_end_to_end", None)
             line["roofline"]["traffic"] = None
             line["roofline"]["flop_per_launch"] = fc1_flops / max(fc1_n, 1)

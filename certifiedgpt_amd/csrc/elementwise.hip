@@ -206,6 +206,34 @@ __global__ __launch_bounds__(256) void noise_batch_kernel(const float* __restric
     }
 }
 
+// One step of the random-gradient-free (RGF) black-box attack against the smoothed classifier (BASELINE configs[4]; the
+// reference describes it in prose only, README.md:62-64,108-120 -- this update rule is build-side):
+//   g[e]   = sum_i coeff[i] * u_{first_dir+i}[e]         (u_s = the N(0,1) draw of sample index s in the noise stream,
+//                                                         i.e. exactly the direction cgpt_noise_batch(x, s, 1, delta) added)
+//   out[e] = clamp(x_adv[e] + lr * sign(g[e]),  x_clean[e] - eps,  x_clean[e] + eps)
+// Separate multiply and add (no contraction), directions in index order: the CPU oracle reproduces the sum bit for bit.
+struct RgfCoeffs { float c[CGPT_RGF_MAX_DIRS]; };
+__global__ __launch_bounds__(256) void rgf_step_kernel(const float* __restrict__ x_adv, const float* __restrict__ x_clean,
+                                                       int64_t chw, int64_t first_dir, int q, RgfCoeffs coeffs, float lr,
+                                                       float eps, uint64_t seed, float* __restrict__ out) {
+    const int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (grp >= (chw + 3) / 4) return;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < q; ++i) {
+        const float4 z = normal4(seed, (uint64_t)(first_dir + i), (uint32_t)grp, 0u);
+        const float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = __fadd_rn(g[k], __fmul_rn(coeffs.c[i], zz[k]));
+    }
+    const int64_t e = grp * 4;
+    for (int k = 0; k < 4 && e + k < chw; ++k) {
+        const float sg = g[k] > 0.f ? 1.f : (g[k] < 0.f ? -1.f : 0.f);
+        const float c = x_clean[e + k];
+        const float v = __fadd_rn(x_adv[e + k], __fmul_rn(lr, sg));
+        out[e + k] = fminf(fmaxf(v, c - eps), c + eps);
+    }
+}
+
 __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
                                 float* __restrict__ resid, int64_t ld, int T, int nb, int D) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -414,6 +442,16 @@ hipError_t launch_noise_batch(const float* x, int64_t chw, int64_t first_sample,
     const int64_t n = ((chw + 3) / 4) * num;
     hipLaunchKernelGGL(noise_batch_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, x, chw, first_sample, num, sigma,
                        seed, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_rgf_step(const float* x_adv, const float* x_clean, int64_t chw, int64_t first_dir, int q, const float* coeffs,
+                           float lr, float eps, uint64_t seed, float* out, hipStream_t stream) {
+    if (q < 0 || q > CGPT_RGF_MAX_DIRS) return hipErrorInvalidValue;
+    RgfCoeffs c;
+    for (int i = 0; i < CGPT_RGF_MAX_DIRS; ++i) c.c[i] = i < q ? coeffs[i] : 0.f;
+    hipLaunchKernelGGL(rgf_step_kernel, dim3(blocks_for((chw + 3) / 4)), dim3(256), 0, stream, x_adv, x_clean, chw, first_dir, q,
+                       c, lr, eps, seed, out);
     return hipGetLastError();
 }
 

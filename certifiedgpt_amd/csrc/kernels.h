@@ -72,6 +72,11 @@ hipError_t launch_im2col(const float* images, int img, int ps, int nb, half_t* A
 // out[b, :] = x + sigma * eps_{first_sample + b}   (fp32 images; handle-free C-ABI cgpt_noise_batch)
 hipError_t launch_noise_batch(const float* x, int64_t chw, int64_t first_sample, int64_t num, float sigma,
                               uint64_t seed, float* out, hipStream_t stream);
+// RGF attack step (build-side rule, see elementwise.hip): out = clamp(x_adv + lr*sign(sum_i coeffs[i]*u_{first_dir+i}), x_clean +- eps);
+// coeffs is a HOST array of q <= CGPT_RGF_MAX_DIRS floats.
+#define CGPT_RGF_MAX_DIRS 32
+hipError_t launch_rgf_step(const float* x_adv, const float* x_clean, int64_t chw, int64_t first_dir, int q, const float* coeffs,
+                           float lr, float eps, uint64_t seed, float* out, hipStream_t stream);
 // resid[b*T + 0, :] = cls + pos[0, :]   (eva_vit.py:337-340, CLS row)
 hipError_t launch_cls_rows(const float* cls, const float* pos, float* resid, int64_t ld, int T, int nb, int D,
                            hipStream_t stream);

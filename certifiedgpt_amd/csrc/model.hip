@@ -615,6 +615,14 @@ cgpt_status cgpt_noise_batch(const float* x_dev, int64_t chw, int64_t first_samp
     return CGPT_OK;
 }
 
+cgpt_status cgpt_rgf_step(const float* x_adv_dev, const float* x_clean_dev, int64_t chw, int64_t first_dir, int32_t num_dirs,
+                          const float* coeffs_host, float lr, float eps, uint64_t noise_seed, float* out_dev, void* stream) {
+    if (!x_adv_dev || !x_clean_dev || !out_dev || !coeffs_host || chw < 1 || num_dirs < 1 || num_dirs > CGPT_RGF_MAX_DIRS || !(eps >= 0.f))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_rgf_step: bad argument (1 <= num_dirs <= 32)");
+    HIPCHK(launch_rgf_step(x_adv_dev, x_clean_dev, chw, first_dir, num_dirs, coeffs_host, lr, eps, noise_seed, out_dev, (hipStream_t)stream));
+    return CGPT_OK;
+}
+
 cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes, int64_t* counts_dev, void* stream) {
     if (!logits_dev || !counts_dev || num < 0 || num_classes < 1) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_vote: bad argument");
     HIPCHK(launch_vote(logits_dev, num_classes, num, num_classes, counts_dev, num, counts_dev, (hipStream_t)stream));

@@ -142,6 +142,14 @@ cgpt_status cgpt_get_activation(cgpt_handle h, const char* what, float* out_dev,
 /* smoothing.py:95-96: out[b] = x + sigma * eps_{first_sample+b}; out_dev is [num,3,H,W] float32.  Handle-free. */
 cgpt_status cgpt_noise_batch(const float* x_dev, int64_t chw, int64_t first_sample, int64_t num, float sigma,
                              uint64_t noise_seed, float* out_dev, void* stream);
+/* One step of the random-gradient-free black-box attack of BASELINE configs[4] (the reference has no code for it, only prose:
+ * README.md:62-64,108-120; the rule is this library's): with u_s the N(0,1) image of sample index s of the noise stream (the
+ * direction cgpt_noise_batch(x, s, 1, delta, seed) adds),
+ *   out = clamp(x_adv + lr * sign(sum_{i<num_dirs} coeffs_host[i] * u_{first_dir+i}), x_clean - eps, x_clean + eps).
+ * coeffs_host: num_dirs (1..32) finite-difference coefficients on the HOST; the three images are [chw] float32 on the device
+ * (out_dev may alias x_adv_dev).  Handle-free. */
+cgpt_status cgpt_rgf_step(const float* x_adv_dev, const float* x_clean_dev, int64_t chw, int64_t first_dir, int32_t num_dirs,
+                          const float* coeffs_host, float lr, float eps, uint64_t noise_seed, float* out_dev, void* stream);
 /* smoothing.py:97-98,101-105: counts_dev[argmax(logits[b,:])] += 1 for b < num (first max index on ties). */
 cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes, int64_t* counts_dev, void* stream);
 

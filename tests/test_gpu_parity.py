@@ -314,3 +314,92 @@ def test_device_side_statistics_match_reference_goldens(stats_golden):
     a = cg.Smooth(clf, K, 0.25, seed=5).certify(x0, 24, 40, 0.05, 16)
     b = cg.Smooth(clf, K, 0.25, seed=5, device_stats=True).certify(x0, 24, 40, 0.05, 16)
     assert a[0] == b[0] and abs(a[1] - b[1]) <= 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ RGF attack
+def test_rgf_step_kernel_matches_oracle_bit_for_bit():
+    """cgpt_rgf_step vs oracle/rgf_oracle.rgf_step on the directions the device itself generates (exported through
+    cgpt_noise_batch with x = 0, sigma = 1), and the direction stream vs the oracle's Philox restatement."""
+    from oracle import rgf_oracle as ro
+    shape = (3, 28, 28)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(shape, generator=g)
+    x_adv = x + 0.1 * torch.randn(shape, generator=g)
+    for first, q, lr, eps in [(0, 1, 0.05, 0.25), (7, 3, -0.02, 0.08), (100, 32, 0.3, 0.2), (5, 2, 0.05, 0.0)]:
+        coeffs = (torch.randn(q, generator=g) * 2).numpy().astype(np.float32)
+        if q == 3:
+            coeffs[1] = 0.0
+        got = cg.rgf_step(x_adv.to(DEV), x.to(DEV), first, coeffs, lr, eps, 77).cpu().numpy()
+        dirs = cg.noise_batch(torch.zeros(shape, device=DEV), first, q, 1.0, 77).cpu().numpy()
+        ref = ro.rgf_step(x_adv.numpy(), x.numpy(), dirs, coeffs, lr, eps)
+        assert np.array_equal(got, ref), (first, q, float(np.abs(got - ref).max()))
+        assert float(np.abs(got - x.numpy()).max()) <= eps + 1e-7
+        # the oracle's own direction stream is the same stream (float32 Box-Muller: compared to 2e-6)
+        od = np.stack([ro.direction(77, first + i, shape) for i in range(q)])
+        assert float(np.abs(od - dirs).max()) <= 2e-6
+    # all-zero coefficients: sign(0) = 0, the image only gets clamped
+    same = cg.rgf_step(x_adv.to(DEV), x.to(DEV), 0, np.zeros(2, np.float32), 0.5, 10.0, 77).cpu().numpy()
+    assert np.array_equal(same, x_adv.numpy())
+
+
+def test_rgf_attack_loop_matches_oracle_loop_and_is_reproducible():
+    """RGFAttack (HIP noise / classifier / vote / update kernels + the host schedule) against oracle/rgf_oracle.attack, the
+    numpy restatement of the schedule, with the vote shares of both coming from the GPU Smooth (so the comparison isolates the
+    loop and the update rule; the classifier itself is covered by the tests above)."""
+    from oracle import rgf_oracle as ro
+    K = 10
+    clf, p16, params, cfg = tiny_pair(mo.MODE_VIT_HEAD, num_classes=K, max_batch=16)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    sigma, seed, n, alpha, bs = 0.25, 5, 32, 0.05, 16
+    s = cg.Smooth(clf, K, sigma, seed=seed)
+    base_counts = s._sample_noise(x0, n, bs)
+    target = int(np.argsort(base_counts)[-2]) if (base_counts > 0).sum() > 1 else (int(base_counts.argmax()) + 1) % K
+    steps, q, delta, lr, eps, dseed = 4, 2, 0.5, 0.05, 0.2, 99
+
+    def run():
+        s.reset(1000)
+        atk = cg.RGFAttack(s, steps=steps, num_dirs=q, delta=delta, lr=lr, eps=eps, dir_seed=dseed)
+        return atk.attack(x0, target, n, alpha, bs, targeted=True)
+
+    x_adv, label, hist = run()
+    x_adv2, label2, hist2 = run()
+    assert torch.equal(x_adv, x_adv2) and label == label2 and hist == hist2          # reproducible bit for bit
+    assert len(hist) == steps + 1 and all(0.0 <= h <= 1.0 for h in hist)
+    assert float((x_adv - x0).abs().max()) <= eps + 1e-6
+    assert label == cg.Smooth.ABSTAIN or 0 <= label < K
+
+    def share_fn(img, step):                                  # same sample indices per step as RGFAttack
+        s.reset(1000 + step * n)
+        c = s._sample_noise(torch.from_numpy(np.ascontiguousarray(img)).to(DEV), n, bs)
+        return float(c[target]) / n
+
+    def direction_fn(i):                                      # the device's own draws
+        return cg.noise_batch(torch.zeros_like(x0), i, 1, 1.0, dseed)[0].cpu().numpy()
+
+    o_adv, o_hist = ro.attack(share_fn, direction_fn, x0.cpu().numpy(), steps, q, delta, lr, eps, targeted=True)
+    assert o_hist == hist, (o_hist, hist)
+    assert np.array_equal(o_adv, x_adv.cpu().numpy())
+    assert cg.RGFAttack(s, steps=8, num_dirs=1).forwards_per_image(100) == 1700
+
+
+def test_attack_eval_agent_runs_the_rgf_scenario(tmp_path):
+    """Plugin contract (launch.py:97-107) of the attack-evaluation agent on the tiny model: BASELINE configs[4] in miniature."""
+    from certifiedgpt_amd.agents import registry, setup_agent
+    from certifiedgpt_amd.agents import minigpt4_attack_agent  # noqa: F401  (import registers)
+    K = 10
+    clf, p16, params, cfg = tiny_pair(mo.MODE_VIT_HEAD, num_classes=K, max_batch=16)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    conf = {"run": {"agent": "image_text_attack_eval", "output_dir": str(tmp_path), "seed": 3,
+                    "smoothing": {"sigma": 0.25, "n": 16, "alpha": 0.05, "batch_size": 16, "num_classes": K},
+                    "attack": {"steps": 3, "num_dirs": 2, "delta": 0.5, "lr": 0.05, "eps": 0.2, "seed": 9}}}
+    registry.register("configuration", conf)
+    agent = setup_agent(conf)
+    agent.classifier = clf
+    agent.dataset = [(x0, 1), (x0 * 0.5, 4)]
+    agent.run()
+    res = agent.finalize()
+    assert res["images"] == 2 and 0.0 <= res["attack_success_rate"] <= 1.0
+    assert res["forwards_per_image"] == (3 * 3 + 1) * 16 + 16
+    lines = open(tmp_path / "attack_eval.tsv").read().strip().splitlines()
+    assert len(lines) == 3 and lines[0].split("\t")[:3] == ["idx", "label", "target"]
+    assert lines[1].split("\t")[2] == "2" and lines[2].split("\t")[2] == "5"

@@ -43,3 +43,21 @@ def test_survey_known_answers():
     assert so.predict_from_counts([60, 40, 0], 0.001) == -1
     assert so.predict_from_counts([90, 10, 0], 0.001) == 0
     assert so.predict_from_counts([50, 50, 0], 0.001) == -1
+
+
+def test_rgf_oracle_step_properties():
+    """oracle/rgf_oracle (build-side rule; the reference has no attack code): eps-ball, sign rule, determinism."""
+    from oracle import rgf_oracle as ro
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 8, 8)).astype(np.float32)
+    dirs = [ro.direction(5, i, x.shape) for i in range(3)]
+    assert np.array_equal(dirs[1], ro.direction(5, 1, x.shape)) and not np.array_equal(dirs[0], dirs[1])
+    out = ro.rgf_step(x, x, dirs, [1.0, 0.0, 0.0], 0.1, 0.25)
+    assert np.allclose(out - x, 0.1 * np.sign(dirs[0]), atol=1e-6)
+    out = ro.rgf_step(x, x, dirs, [0.5, -2.0, 0.25], 1.0, 0.25)
+    assert float(np.abs(out - x).max()) <= 0.25 + 1e-7
+    # a share function that rewards moving along +dirs[0] is ascended by the targeted loop
+    u0 = dirs[0]
+    share = lambda img, step: float(1.0 / (1.0 + np.exp(-np.sum((img - x) * u0) / 50.0)))
+    adv, hist = ro.attack(share, lambda i: ro.direction(5, i, x.shape), x, steps=6, num_dirs=4, delta=0.5, lr=0.05, eps=0.5)
+    assert hist[-1] > hist[0] and len(hist) == 7
