@@ -6,7 +6,9 @@ sigma = 0.5 through EVA-ViT-G (random-init weights of that architecture) + ln_vi
 (BASELINE.json configs[1]); i.e. n0 + n = 200 classifier forwards (reference smoothing.py:44,48).
 With N GPUs the Monte-Carlo samples of every `_sample_noise` are sharded over the ranks and the int64 vote histograms are
 summed with one RCCL all-reduce (strong scaling: the work per certified image is fixed).  The n0 selection draws and the n
-estimation draws are independent, so `certify` runs them in the same classifier batches (batch_size = (n0+n)/N per GPU).
+estimation draws are independent, so `certify` runs them in the same classifier batches; a rank's slice of one image is
+(n0+n)/N draws, and `Smooth.certify_many` lets the slices of N consecutive images share one 200-sample classifier batch and
+one all-reduce (same sample indices and counts as N separate `certify` calls; `config.images_per_pass`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
     (extra, NON-headline data points: --workload encode_img | rgf, --img-size 448, --n 1000 / --n0 K)
@@ -115,7 +117,11 @@ def main():
     def _share(r):
         a, b = cg.shard_range(n_sel, r, world), cg.shard_range(n_est, r, world, mirrored=True)
         return (a[1] - a[0]) + (b[1] - b[0])
-    per_gpu = min(max(_share(r) for r in range(world)), 200)          # 25 at 8 GPUs (13 + 12 on every rank)
+    share = max(_share(r) for r in range(world))                      # 25 at 8 GPUs (13 + 12 on every rank)
+    per_gpu = 200 if world > 1 else min(share, 200)                   # classifier batch capacity per GPU
+    # With several GPUs a rank owns only share = (n0+n)/world draws of an image; Smooth.certify_many lets the slices of
+    # `group` images share one classifier batch (and one all-reduce), so every GPU keeps running 200-sample batches.
+    group = max(1, per_gpu // share) if (world > 1 and not rgf) else 1
     clf = cg.HipClassifier(mode=mode, num_classes=NUM_CLASSES, max_batch=per_gpu, device=local, img_size=args.img_size)
     clf.init_synthetic(seed=0)                                         # identical weights on every rank
     smooth = cg.Smooth(clf, NUM_CLASSES, SIGMA, seed=42)
@@ -134,17 +140,22 @@ def main():
             return label, hist[-1]
         return smooth.certify(img, n_sel, n_est, ALPHA, per_gpu)
 
-    results = []
-    for i in range(args.warmup):
-        results.append(step(images[i]))
+    def run(lo, hi):
+        out, i = [], lo
+        while i < hi:
+            g = min(group, hi - i)
+            out += smooth.certify_many(images[i:i + g], n_sel, n_est, ALPHA, per_gpu) if g > 1 else [step(images[i])]
+            i += g
+        return out
+
+    results = run(0, args.warmup)
     torch.cuda.synchronize()
     clf.profile_read(0)
     clf.profile(True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        results.append(step(images[args.warmup + i]))
+    results += run(args.warmup, args.warmup + args.steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -185,7 +196,9 @@ def main():
                                    "image, Smooth.certify n0=100 n=100 alpha=0.001 sigma=0.5 (BASELINE configs[1])",
                        "n0": N0, "n": N, "alpha": ALPHA, "sigma": SIGMA, "num_classes": NUM_CLASSES,
                        "batch_size_per_gpu": per_gpu, "forwards_per_image": N0 + N,
-                       "parallelism": f"sample-sharded x{world}, one int64[2,{NUM_CLASSES}] all-reduce per certify"},
+                       "images_per_pass": group,
+                       "parallelism": (f"sample-sharded x{world}: every rank draws its slice of each image's n0 and n samples; "
+                                       f"{group} image(s) per fused pass, one int64[{group},2,{NUM_CLASSES}] all-reduce per pass")},
             "forwards_per_s": value * (N0 + N),
             "vit_tflops_end_to_end": value * (N0 + N) * F_VIT / 1e12,
             "roofline": {"bound": "mfma", "kernel": "gemm3_f16_kernel<EPI_F16_GELU, 4> (ViT MLP fc1 + GELU, M=batch*257, N=6144, K=1408)",

@@ -46,6 +46,7 @@ SIGNATURES = {
     "cgpt_init_synthetic_weights": (_I32, [_P, _U64, _P]),
     "cgpt_sample_counts": (_I32, [_P, _P, _I64, _I64, _I64, _F, _U64, _P, _P]),
     "cgpt_sample_counts2": (_I32, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _F, _U64, _P]),
+    "cgpt_sample_counts_images": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _F, _U64, _P]),
     "cgpt_forward_logits": (_I32, [_P, _P, _I64, _I64, _F, _U64, _P, _P]),
     "cgpt_classify": (_I32, [_P, _P, _I64, _P, _P]),
     "cgpt_get_activation": (_I32, [_P, C.c_char_p, _P, _I64, _P]),

@@ -6,7 +6,8 @@ log one line per sample (idx, label, predict, radius, correct, time -- the forma
 
 Config (a plain dict or any mapping; the reference's YAMLs define no smoothing keys, so these are build-side):
     run:   {agent: image_text_certify, output_dir: ..., seed: 0,
-            smoothing: {sigma: 0.5, n0: 100, n: 100, alpha: 0.001, batch_size: 100, num_classes: 1000, radii: [0.25, 0.5, 1.0]}}
+            smoothing: {sigma: 0.5, n0: 100, n: 100, alpha: 0.001, batch_size: 100, num_classes: 1000, radii: [0.25, 0.5, 1.0],
+                        images_per_pass: 1}}      # > 1: Smooth.certify_many (multi-GPU throughput mode)
     model: {mode: vit_head | encode_img, weights: <path to a torch state_dict saved with torch.save> | null, dims: {...}}
     data:  {num_images: 10, seed: 1234}      # synthetic CLIP-normalised images unless `dataset` is passed to the agent
 """
@@ -42,13 +43,7 @@ class CertifyLoop:
         header = "idx\tlabel\tpredict\tradius\tcorrect\ttime" if mode == "certify" else "idx\tlabel\tpredict\tcorrect\ttime"
         if f:
             print(header, file=f, flush=True)
-        for idx, (x, label) in enumerate(dataset):
-            t0 = time.perf_counter()
-            if mode == "certify":
-                pred, radius = smooth.certify(x, sm_cfg["n0"], sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"])
-            else:
-                pred, radius = smooth.predict(x, sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"]), 0.0
-            dt = time.perf_counter() - t0
+        def emit(idx, label, pred, radius, dt):
             rec = dict(idx=idx, label=int(label), predict=int(pred), radius=float(radius), correct=int(pred == label), time=dt)
             self.records.append(rec)
             if f:
@@ -56,6 +51,35 @@ class CertifyLoop:
                     print(f"{idx}\t{label}\t{pred}\t{radius:.6f}\t{rec['correct']}\t{dt:.3f}", file=f, flush=True)
                 else:
                     print(f"{idx}\t{label}\t{pred}\t{rec['correct']}\t{dt:.3f}", file=f, flush=True)
+
+        # images_per_pass > 1 (certify only): Smooth.certify_many runs the per-rank sample slices of several images in one
+        # classifier batch and one all-reduce -- the multi-GPU throughput mode; results equal the one-by-one loop.
+        group = int(sm_cfg.get("images_per_pass", 1)) if mode == "certify" else 1
+        pending = []
+
+        def flush():
+            if not pending:
+                return
+            t0 = time.perf_counter()
+            outs = smooth.certify_many(torch.stack([p[1] for p in pending]), sm_cfg["n0"], sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"])
+            dt = (time.perf_counter() - t0) / len(pending)
+            for (idx, _, label), (pred, radius) in zip(pending, outs):
+                emit(idx, label, pred, radius, dt)
+            pending.clear()
+
+        for idx, (x, label) in enumerate(dataset):
+            if group > 1:
+                pending.append((idx, x, label))
+                if len(pending) == group:
+                    flush()
+                continue
+            t0 = time.perf_counter()
+            if mode == "certify":
+                pred, radius = smooth.certify(x, sm_cfg["n0"], sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"])
+            else:
+                pred, radius = smooth.predict(x, sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"]), 0.0
+            emit(idx, label, pred, radius, time.perf_counter() - t0)
+        flush()
         if f:
             f.close()
         return self.records

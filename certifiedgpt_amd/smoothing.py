@@ -99,6 +99,31 @@ class Smooth(object):
         c = counts.cpu().numpy().astype(int)
         return c[0], c[1]
 
+    def certify_many(self, xs, n0: int, n: int, alpha: float, batch_size: int):
+        """`certify` for a stack of images xs[G,3,H,W]: the list of (label, radius) that G consecutive `certify` calls
+        return (same sample indices, bit-identical counts), computed as ONE fused pass.  Each rank still owns its
+        shard_range slice of every image's n0 and n draws, but the slices of several images share a classifier batch
+        (floor(batch capacity / slice) images at a time) and all G x 2 histograms travel in one all-reduce: at 8 GPUs a rank
+        runs 8 x 25-sample slices per batch instead of one, i.e. the same GEMM shapes as a single GPU."""
+        bc = self.base_classifier
+        G = int(xs.shape[0])
+        if not hasattr(bc, "sample_counts_images") or G <= 1:
+            return [self.certify(xs[i], n0, n, alpha, batch_size) for i in range(G)]
+        bc.eval()
+        first = self._next_sample
+        self._next_sample += G * (n0 + n)
+        rank, world = _world(self.process_group)
+        lo_a, hi_a = shard_range(n0, rank, world)
+        lo_b, hi_b = shard_range(n, rank, world, mirrored=True)
+        with torch.no_grad():
+            counts = bc.sample_counts_images(xs, first + lo_a, hi_a - lo_a, first + n0 + lo_b, hi_b - lo_b, n0 + n,
+                                             float(self.sigma), self.seed)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
+        c = counts.cpu().numpy().astype(int)
+        return [self.certify_from_counts(c[i, 0], c[i, 1], n, alpha) for i in range(G)]
+
     def predict(self, x: torch.tensor, n: int, alpha: float, batch_size: int) -> int:
         """smoothing.py:58-79.  Returns the predicted class or ABSTAIN."""
         self.base_classifier.eval()

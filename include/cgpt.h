@@ -125,6 +125,15 @@ cgpt_status cgpt_sample_counts(cgpt_handle h, const float* x_dev, int64_t first_
 cgpt_status cgpt_sample_counts2(cgpt_handle h, const float* x_dev, int64_t first_a, int64_t num_a, int64_t* counts_a_dev,
                                 int64_t first_b, int64_t num_b, int64_t* counts_b_dev, int64_t batch_size, float sigma,
                                 uint64_t noise_seed, void* stream);
+/* The same pass for SEVERAL images at once: image i (x_dev + i*3*H*W) draws samples first_a + i*image_stride + [0, num_a)
+ * and first_b + i*image_stride + [0, num_b), exactly what num_images consecutive Smooth.certify calls would use with
+ * image_stride = n0 + n.  counts_dev is int64 [num_images, 2, num_classes] (selection row, estimation row), ADDED into.
+ * num_a + num_b <= max_batch; floor(max_batch / (num_a + num_b)) images share one classifier batch, so a rank that owns
+ * only a thin slice of every image's samples (N/8 on 8 GPUs) still runs full batches.  Counts are bit-identical to the
+ * per-image calls. */
+cgpt_status cgpt_sample_counts_images(cgpt_handle h, const float* x_dev, int64_t num_images, int64_t first_a, int64_t num_a,
+                                      int64_t first_b, int64_t num_b, int64_t image_stride, int64_t* counts_dev, float sigma,
+                                      uint64_t noise_seed, void* stream);
 /* Same batches, but return the logits [num, num_classes] float32 instead of voting (parity tests; num <= max_batch). */
 cgpt_status cgpt_forward_logits(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num,
                                 float sigma, uint64_t noise_seed, float* logits_dev, void* stream);

@@ -53,6 +53,22 @@ def test_agent_contract(tmp_path, agent_name):
     assert json.load(open(tmp_path / f"{mode}_summary.json"))["images"] == 3
 
 
+def test_grouped_certify_gives_the_same_records(tmp_path):
+    """images_per_pass > 1 routes through Smooth.certify_many; an engine without the several-images protocol falls back to
+    consecutive certify calls, so the log is the same as the one-by-one loop."""
+    outs = []
+    for group in (1, 2):
+        cfg = _config(tmp_path / f"g{group}", "image_text_certify")
+        cfg["run"]["smoothing"]["images_per_pass"] = group
+        registry.register("configuration", cfg)
+        agent = setup_agent(cfg)
+        agent.classifier = Engine()
+        agent.dataset = [(torch.zeros(3, 8, 8), 2), (torch.zeros(3, 8, 8), 1), (torch.zeros(3, 8, 8), 2)]
+        agent.run()
+        outs.append([(r["idx"], r["label"], r["predict"], r["radius"]) for r in agent.records])
+    assert outs[0] == outs[1] and len(outs[0]) == 3
+
+
 def test_duplicate_registration_rejected():
     with pytest.raises(KeyError):
         @registry.register_agent("image_text_certify")

@@ -43,6 +43,47 @@ class PairEngine(IndexedEngine):
         return torch.stack([a, b])
 
 
+class ImagesEngine(PairEngine):
+    """Adds the several-images protocol (HipClassifier.sample_counts_images); votes also depend on the image."""
+
+    def sample_counts_images(self, xs, first_a, num_a, first_b, num_b, image_stride, sigma, seed):
+        out = []
+        for i in range(xs.shape[0]):
+            out.append(self.sample_counts_pair(xs[i], first_a + i * image_stride, num_a, first_b + i * image_stride, num_b, 1 << 30, sigma, seed))
+        return torch.stack(out)
+
+
+def _many_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = cg.Smooth(ImagesEngine(), K, 0.5, seed=11)
+        xs = torch.zeros(3, 3, 8, 8)
+        q.put((rank, s.certify_many(xs, 51, 77, 0.01, 16), s._next_sample))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_certify_many_two_ranks_equals_consecutive_single_process_certify():
+    ref = cg.Smooth(IndexedEngine(), K, 0.5, seed=11)
+    xs = torch.zeros(3, 3, 8, 8)
+    expect = [ref.certify(xs[i], 51, 77, 0.01, 16) for i in range(3)]
+    one = cg.Smooth(ImagesEngine(), K, 0.5, seed=11)
+    assert one.certify_many(xs, 51, 77, 0.01, 16) == expect and one._next_sample == ref._next_sample == 3 * 128
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_many_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, cursor in got:
+        assert out == expect and cursor == 3 * 128, (rank, out, expect)
+
+
 def _single():
     s = cg.Smooth(IndexedEngine(), K, 0.5, seed=11)
     x = torch.zeros(3, 8, 8)

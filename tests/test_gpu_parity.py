@@ -403,3 +403,26 @@ def test_attack_eval_agent_runs_the_rgf_scenario(tmp_path):
     lines = open(tmp_path / "attack_eval.tsv").read().strip().splitlines()
     assert len(lines) == 3 and lines[0].split("\t")[:3] == ["idx", "label", "target"]
     assert lines[1].split("\t")[2] == "2" and lines[2].split("\t")[2] == "5"
+
+
+def test_certify_many_is_bit_identical_to_consecutive_certify_calls():
+    """Several images per fused pass (cgpt_sample_counts_images): same sample indices, same counts, same decisions as the
+    per-image calls -- for full groups, a ragged last group, and a per-image share larger than the batch capacity."""
+    K = 10
+    clf, p16, params, cfg = tiny_pair(mo.MODE_ENCODE_IMG, num_classes=K, max_batch=16)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    xs = torch.stack([torch.from_numpy(mo.synthetic_image(cfg)) * (0.5 + 0.25 * i) + 0.1 * torch.randn(3, cfg.img_size, cfg.img_size, generator=g)
+                      for i in range(5)]).to(DEV)
+    for (n0, n) in [(3, 4), (5, 3), (2, 6), (12, 20)]:            # 2 / 2 / 2 images per batch of 16; last: one image > capacity
+        s1 = cg.Smooth(clf, K, 0.25, seed=5)
+        s2 = cg.Smooth(clf, K, 0.25, seed=5)
+        seq = [s1.certify(xs[i], n0, n, 0.05, 16) for i in range(5)]
+        many = s2.certify_many(xs, n0, n, 0.05, 16)
+        assert many == seq, (n0, n, many, seq)
+        assert s1._next_sample == s2._next_sample == 5 * (n0 + n)
+    # raw counts: [G, 2, K] table vs the pair pass per image
+    tab = clf.sample_counts_images(xs, 7, 3, 100, 4, 11, 0.25, 5)
+    for i in range(5):
+        pair = clf.sample_counts_pair(xs[i], 7 + 11 * i, 3, 100 + 11 * i, 4, 16, 0.25, 5)
+        assert torch.equal(tab[i], pair), i
+    assert int(tab.sum()) == 5 * 7

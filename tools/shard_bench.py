@@ -30,6 +30,17 @@ def main():
         base = base or ms
         print(f"world {world}: {na + nb:3d} samples/rank  {ms:8.2f} ms/certify-shard  gemms {gms / it:7.2f} ms ({gfl / gms / 1e9:5.0f} TF)"
               f"  non-gemm {ms - gms / it:6.2f} ms   speed-up ceiling {base / ms:4.2f}x", flush=True)
+        if world > 1:      # Smooth.certify_many: the slices of `world` images share one 200-sample batch (bench.py at N > 1)
+            xs = torch.stack([x * (1.0 - 0.01 * i) for i in range(world)])
+            for _ in range(2):
+                clf.sample_counts_images(xs, 0, na, 100, nb, 200, 0.5, 42)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); it2 = 4
+            for _ in range(it2):
+                clf.sample_counts_images(xs, 0, na, 100, nb, 200, 0.5, 42)
+            torch.cuda.synchronize()
+            msg = (time.perf_counter() - t0) / it2 * 1e3 / world
+            print(f"         grouped: {world} images per pass  {msg:8.2f} ms/certify-shard   speed-up ceiling {base / msg:4.2f}x", flush=True)
     clf.close()
 
 if __name__ == "__main__":
