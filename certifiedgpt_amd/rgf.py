@@ -69,13 +69,14 @@ class RGFAttack(object):
         history = []
         sign = 1.0 if targeted else -1.0
         for _ in range(self.steps):
-            base, _ = self._share(x_adv, label, n, batch_size, cursor)
+            # x_adv and its q probes go through the classifier together, all under the same n noise draws
+            probes = [noise_batch(x_adv, self._next_dir + i, 1, self.delta, self.dir_seed)[0] for i in range(self.num_dirs)]
+            self.smooth.reset(cursor)
+            counts = self.smooth.sample_noise_many(torch.stack([x_adv] + probes), n, batch_size, common_noise=True)
+            shares = counts[:, label].astype(np.float64) / float(n)
+            base = float(shares[0])
             history.append(base)
-            coeffs = []
-            for i in range(self.num_dirs):
-                xq = noise_batch(x_adv, self._next_dir + i, 1, self.delta, self.dir_seed)[0]
-                s, _ = self._share(xq, label, n, batch_size, cursor)
-                coeffs.append((s - base) / self.delta)
+            coeffs = [(float(shares[1 + i]) - base) / self.delta for i in range(self.num_dirs)]
             x_adv = rgf_step(x_adv, x, self._next_dir, coeffs, sign * self.lr, self.eps, self.dir_seed)
             self._next_dir += self.num_dirs
             cursor += n

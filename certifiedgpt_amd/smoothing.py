@@ -124,6 +124,32 @@ class Smooth(object):
         c = counts.cpu().numpy().astype(int)
         return [self.certify_from_counts(c[i, 0], c[i, 1], n, alpha) for i in range(G)]
 
+    def sample_noise_many(self, xs, num: int, batch_size, common_noise: bool = True) -> np.ndarray:
+        """`_sample_noise` for a stack of images -> int array [G, num_classes].  common_noise=True: every image sees the
+        SAME `num` noise draws (sample indices cursor .. cursor+num-1, consumed once): the finite differences of a query
+        attack then measure the images, not the Monte-Carlo draw.  False: image i uses the next `num` indices after image
+        i-1, as G consecutive `_sample_noise` calls would."""
+        bc = self.base_classifier
+        G = int(xs.shape[0])
+        first = self._next_sample
+        stride = 0 if common_noise else num
+        if not hasattr(bc, "sample_counts_images"):
+            out = []
+            for i in range(G):
+                self._next_sample = first + i * stride
+                out.append(self._sample_noise(xs[i], num, batch_size))
+            self._next_sample = first + (num if common_noise else G * num)
+            return np.stack(out)
+        self._next_sample = first + (num if common_noise else G * num)
+        rank, world = _world(self.process_group)
+        lo, hi = shard_range(num, rank, world)
+        with torch.no_grad():
+            counts = bc.sample_counts_images(xs, first + lo, hi - lo, 0, 0, stride, float(self.sigma), self.seed)[:, 0].contiguous()
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
+        return counts.cpu().numpy().astype(int)
+
     def predict(self, x: torch.tensor, n: int, alpha: float, batch_size: int) -> int:
         """smoothing.py:58-79.  Returns the predicted class or ABSTAIN."""
         self.base_classifier.eval()
