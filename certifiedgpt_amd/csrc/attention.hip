@@ -235,10 +235,21 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         }
     };
 
+#ifdef CGPT_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long stamp_begin = __builtin_amdgcn_s_memtime();
+#define CGPT_ASTAMP(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ph[k] += tn - tlast; tlast = tn; }
+#else
+#define CGPT_ASTAMP(k)
+#endif
     // ---- persistent walk over (sample, head) items
     int item = blockIdx.x;
     if (item < nitems) request_kv(item, false);
     for (; item < nitems; item += gridDim.x) {
+#ifdef CGPT_STAMPS
+        unsigned long long tlast = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         const int h = item % p.heads, b = item / p.heads;
         Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
         Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
@@ -254,6 +265,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
             if (idx < TKP * CH) *reinterpret_cast<f16x8*>(Ks + row * KROW + k_chunk_pos<DPAD>(row, ch) * 8) = valid ? sreg[it] : zero8;
         }
         __syncthreads();
+        CGPT_ASTAMP(0)                                   // K -> LDS + barrier
         request_kv(item, true);                          // V of this item; lands under the first QK^T + softmax
         // first query tile of every wave: QK^T + softmax run before V is needed in LDS
         if (have) {
@@ -261,6 +273,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
             if (qt + NWAVES < nqt) request_q(qt + NWAVES);
             qk_softmax();
         }
+        CGPT_ASTAMP(1)                                   // first QK^T + softmax
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int idx = tid + it * NT;
@@ -273,17 +286,28 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
             if (idx < TKP * CH) *reinterpret_cast<f16x8*>(Vs + row * VSTR + ch * 8) = vv;
         }
         __syncthreads();
+        CGPT_ASTAMP(2)                                   // V -> LDS (incl. waiting for its loads) + barrier
         // the staging registers are free: request the NEXT item's K now; it lands during the rest of this item
         if (item + (int)gridDim.x < nitems) request_kv(item + gridDim.x, false);
         if (have) pv_store(qt);
+        CGPT_ASTAMP(3)                                   // first P.V + store
         for (qt += NWAVES; qt < nqt; qt += NWAVES) {
             take_q();
             if (qt + NWAVES < nqt) request_q(qt + NWAVES);
             qk_softmax();
             pv_store(qt);
         }
+        CGPT_ASTAMP(4)                                   // remaining query tiles of this wave
         __syncthreads();                               // every wave is done with this item's LDS images
+        CGPT_ASTAMP(5)                                   // waiting for the slowest wave
     }
+#ifdef CGPT_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        d[0] = __builtin_amdgcn_s_memtime() - stamp_begin;
+        for (int k = 0; k < 6; ++k) d[1 + k] = ph[k];
+    }
+#endif
 }
 
 
@@ -532,7 +556,9 @@ hipError_t launch_one(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
-hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+hipError_t launch_attention(const AttnParams& p_in, hipStream_t stream) {
+    AttnParams p = p_in;
+    p.dbg = g_gemm_dbg;                             // diagnostic stamp buffer (null outside -DCGPT_STAMPS experiments)
     if (p.B <= 0 || p.heads <= 0 || p.Tq <= 0 || p.Tk <= 0) return hipErrorInvalidValue;
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8)) return hipErrorInvalidValue;   // 16-byte row alignment
     const bool small = p.Tk <= 32;

@@ -47,6 +47,7 @@ struct AttnParams {
     half_t* O; int64_t ldo; int64_t o_batch_stride;
     int B, heads, head_dim, Tq, Tk;
     float scale;
+    unsigned long long* dbg = nullptr;   // diagnostic builds only (-DCGPT_STAMPS): per-wave phase cycle sums
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 
