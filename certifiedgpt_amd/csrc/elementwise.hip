@@ -24,13 +24,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 // With `delta` (fp16) the kernel first applies the pending residual update x += delta and writes x back: the
 // reference's `x = x + attn(...)` / `x = x + mlp(...)` (eva_vit.py:180-181), where under autocast the branch output is
 // an fp16 tensor added to the fp32 stream -- done here instead of as a read-modify-write in the GEMM epilogue.
+// Two pending updates (delta, then delta2, added in that order) and keep_x (normalise x + delta [+ delta2] but leave x as it
+// is) let a transformer block write the fp32 stream ONCE: LN1 reads x + (previous fc2 output) without writing, LN2 reads
+// x + (previous fc2 output) + (this block's proj output) and writes the sum -- same additions in the same order.
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int64_t ldx,
                                                         const half_t* __restrict__ delta, int64_t ldd,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         half_t* __restrict__ y16, int64_t ldy16,
-                                                        float* __restrict__ y32, int64_t ldy32, int64_t rows, int D) {
+                                                        float* __restrict__ y32, int64_t ldy32, int64_t rows, int D,
+                                                        const half_t* __restrict__ delta2, int64_t ldd2, int keep_x) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -46,8 +50,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
             const f16x2 d = *reinterpret_cast<const f16x2*>(delta + row * ldd + col);
             v[c].x += (float)d[0];
             v[c].y += (float)d[1];
-            *reinterpret_cast<float2*>(xr + col) = v[c];
         }
+        if (delta2 && col < D) {
+            const f16x2 d = *reinterpret_cast<const f16x2*>(delta2 + row * ldd2 + col);
+            v[c].x += (float)d[0];
+            v[c].y += (float)d[1];
+        }
+        if ((delta || delta2) && !keep_x && col < D) *reinterpret_cast<float2*>(xr + col) = v[c];
         s += v[c].x + v[c].y;
     }
     const float mean = wave_sum(s) / (float)D;
@@ -85,7 +94,8 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(float* __restrict__ x, 
                                                          const half_t* __restrict__ delta, int64_t ldd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, half_t* __restrict__ y16, int64_t ldy16,
-                                                         float* __restrict__ y32, int64_t ldy32, int64_t rows, int D) {
+                                                         float* __restrict__ y32, int64_t ldy32, int64_t rows, int D,
+                                                         const half_t* __restrict__ delta2, int64_t ldd2, int keep_x) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int l32 = threadIdx.x & 31;
     const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -101,8 +111,12 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(float* __restrict__ x, 
         if (delta) {
             const f16x4 d = *reinterpret_cast<const f16x4*>(delta + rr * ldd + col);
             v[c].x += (float)d[0]; v[c].y += (float)d[1]; v[c].z += (float)d[2]; v[c].w += (float)d[3];
-            if (live) *reinterpret_cast<float4*>(xr + col) = v[c];
         }
+        if (delta2) {
+            const f16x4 d = *reinterpret_cast<const f16x4*>(delta2 + rr * ldd2 + col);
+            v[c].x += (float)d[0]; v[c].y += (float)d[1]; v[c].z += (float)d[2]; v[c].w += (float)d[3];
+        }
+        if ((delta || delta2) && !keep_x && live) *reinterpret_cast<float4*>(xr + col) = v[c];
         s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
     }
 #pragma unroll
@@ -394,14 +408,14 @@ hipError_t launch_add_delta(float* x, int64_t ldx, const half_t* delta, int64_t 
 
 hipError_t launch_layernorm(float* x, int64_t ldx, const half_t* delta, int64_t ldd, const float* gamma,
                             const float* beta, float eps, half_t* y16, int64_t ldy16, float* y32, int64_t ldy32,
-                            int64_t rows, int D, hipStream_t stream) {
+                            int64_t rows, int D, hipStream_t stream, const half_t* delta2, int64_t ldd2, int keep_x) {
     if (rows <= 0) return hipSuccess;
-    if (D <= 0 || (D & 1) || D > 32 * 128 || (ldx & 1) || (ldy16 & 1) || (ldy32 & 1) || (ldd & 1)) return hipErrorInvalidValue;
+    if (D <= 0 || (D & 1) || D > 32 * 128 || (ldx & 1) || (ldy16 & 1) || (ldy32 & 1) || (ldd & 1) || (ldd2 & 1)) return hipErrorInvalidValue;
     // 16-byte path: D a multiple of 128 (1408 = 11 x 128, 768 = 6 x 128, 4096) and 16-byte aligned rows
-    if ((D % 128) == 0 && D / 128 <= 32 && (ldx % 4) == 0 && (ldd % 4) == 0 && (ldy16 % 4) == 0 && (ldy32 % 4) == 0) {
+    if ((D % 128) == 0 && D / 128 <= 32 && (ldx % 4) == 0 && (ldd % 4) == 0 && (ldd2 % 4) == 0 && (ldy16 % 4) == 0 && (ldy32 % 4) == 0) {
         dim3 grid4((unsigned)((rows + 7) / 8)), block4(256);
 #define CGPT_LN4(NCH) hipLaunchKernelGGL(layernorm4_kernel<NCH>, grid4, block4, 0, stream, x, ldx, delta, ldd, gamma, beta, eps, \
-                                         y16, ldy16, y32, ldy32, rows, D)
+                                         y16, ldy16, y32, ldy32, rows, D, delta2, ldd2, keep_x)
         const int n = D / 128;
         if (n <= 1) CGPT_LN4(1);
         else if (n <= 6) { if (n == 6) CGPT_LN4(6); else goto generic; }
@@ -414,7 +428,7 @@ hipError_t launch_layernorm(float* x, int64_t ldx, const half_t* delta, int64_t 
 generic:
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define CGPT_LN(NCH) hipLaunchKernelGGL(layernorm_kernel<NCH>, grid, block, 0, stream, x, ldx, delta, ldd, gamma, beta, eps, \
-                                        y16, ldy16, y32, ldy32, rows, D)
+                                        y16, ldy16, y32, ldy32, rows, D, delta2, ldd2, keep_x)
     if (D <= 2 * 128) CGPT_LN(2);
     else if (D <= 6 * 128) CGPT_LN(6);
     else if (D <= 11 * 128) CGPT_LN(11);

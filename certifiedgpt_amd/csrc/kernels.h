@@ -57,7 +57,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 // delta (fp16, may be null): pending residual update, applied first and written back: x += delta (eva_vit.py:180-181).
 hipError_t launch_layernorm(float* x, int64_t ldx, const half_t* delta, int64_t ldd, const float* gamma,
                             const float* beta, float eps, half_t* y16, int64_t ldy16, float* y32, int64_t ldy32,
-                            int64_t rows, int D, hipStream_t stream);
+                            int64_t rows, int D, hipStream_t stream, const half_t* delta2 = nullptr, int64_t ldd2 = 0,
+                            int keep_x = 0);   // delta2: second pending update; keep_x: do not write x + updates back
 // x += delta without a LayerNorm (after the last block).
 hipError_t launch_add_delta(float* x, int64_t ldx, const half_t* delta, int64_t ldd, int64_t rows, int D,
                             hipStream_t stream);

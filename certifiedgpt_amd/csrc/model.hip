@@ -82,7 +82,7 @@ struct cgpt_model {
     std::vector<VitLayer> vit;
     std::vector<QfLayer> qf;
     // workspace
-    half_t *Apatch, *xn, *qkv, *attn, *hid, *delta, *cls16, *emb, *kv_all, *qh16, *qqkv, *qctx, *qq, *qff, *pooled;
+    half_t *Apatch, *xn, *qkv, *attn, *hid, *delta, *delta2, *cls16, *emb, *kv_all, *qh16, *qqkv, *qctx, *qq, *qff, *pooled;
     float *resid, *logits, *qemb0, *qh32, *qtmp, *llama;
     int last_nb = 0;
     bool profile = false;
@@ -263,6 +263,7 @@ cgpt_status build(cgpt_model* m) {
     CGCHK(new_act16(m, M, D, &m->attn));
     CGCHK(new_act16(m, M, m->mlp, &m->hid));
     CGCHK(new_act16(m, M, D, &m->delta));
+    CGCHK(new_act16(m, M, D, &m->delta2));
     CGCHK(new_act16(m, nb, D, &m->cls16));
     CGCHK(new_act32(m, nb, m->K, &m->logits));
     if (full) {
@@ -330,16 +331,20 @@ cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_s
     HIPCHK(launch_cls_rows(m->cls, m->pos, m->resid, D, T, nb, D, st));
     const int hd = D / c.vit_heads;
     // Residual adds (x = x + attn(..), x = x + mlp(..), eva_vit.py:180-181) are deferred: proj / fc2 write their fp16
-    // output to `delta` (the reference's autocast Linear output is fp16 too) and the NEXT LayerNorm kernel applies
-    // resid += delta while it reads the row anyway; no GEMM epilogue reads the fp32 stream.
+    // output to `delta2` / `delta` (the reference's autocast Linear output is fp16 too) and the LayerNorm kernels apply them
+    // while they read the row anyway; no GEMM epilogue reads the fp32 stream.  The stream is WRITTEN once per block: LN1
+    // normalises resid + delta (the previous block's fc2 output) without storing the sum, LN2 normalises and stores
+    // resid + delta + delta2 (this block's proj output) -- the same fp32 additions in the same order as two stores.
     for (int i = 0; i < c.vit_depth; ++i) {                                   // Block.forward, eva_vit.py:178-185
         const VitLayer& L = m->vit[i];
-        HIPCHK(launch_layernorm(m->resid, D, i ? m->delta : nullptr, Dk, L.n1w, L.n1b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st));
+        HIPCHK(launch_layernorm(m->resid, D, i ? m->delta : nullptr, Dk, L.n1w, L.n1b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st,
+                                nullptr, 0, /*keep_x=*/1));
         CGCHK(gemm(m, EPI_F16, m->xn, Dk, L.Wqkv, Dk, L.bqkv, m->qkv, m->ld_qkv, nullptr, 0, M, 3 * D, Dk, 0, st));
         CGCHK(attention(m->qkv, m->ld_qkv, (int64_t)T * m->ld_qkv, m->qkv + D, m->ld_qkv, m->qkv + 2 * D, m->ld_qkv,
                         (int64_t)T * m->ld_qkv, m->attn, Dk, (int64_t)T * Dk, nb, c.vit_heads, hd, T, T, st));
-        CGCHK(gemm(m, EPI_F16, m->attn, Dk, L.Wproj, Dk, L.bproj, m->delta, Dk, nullptr, 0, M, D, Dk, 0, st));
-        HIPCHK(launch_layernorm(m->resid, D, m->delta, Dk, L.n2w, L.n2b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st));
+        CGCHK(gemm(m, EPI_F16, m->attn, Dk, L.Wproj, Dk, L.bproj, m->delta2, Dk, nullptr, 0, M, D, Dk, 0, st));
+        HIPCHK(launch_layernorm(m->resid, D, i ? m->delta : nullptr, Dk, L.n2w, L.n2b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st,
+                                m->delta2, Dk, 0));
         CGCHK(gemm(m, EPI_F16_GELU, m->xn, Dk, L.Wfc1, Dk, L.bfc1, m->hid, m->mlp_k, nullptr, 0, M, m->mlp, Dk, 1, st));
         CGCHK(gemm(m, EPI_F16, m->hid, m->mlp_k, L.Wfc2, m->mlp_k, L.bfc2, m->delta, Dk, nullptr, 0, M, D, m->mlp_k, 0, st));
     }
