@@ -98,14 +98,16 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
     float sum = 1.f;
     f16x8 qf[NDS], qnext[NDS];
     // Q^T B-fragments of query tile qt: lane holds Q[query r15][d = 32*ds + 8*g .. +7] (zero beyond HD)
-    auto request_q = [&](int qt) {
+    auto request_q_from = [&](const half_t* qbase, int qt) {
         const int qrow = min(qt * 16 + r15, p.Tq - 1);
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
             const int d = min(ds * 32 + g * 8, HD - 8);
-            qnext[ds] = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
+            qnext[ds] = *reinterpret_cast<const f16x8*>(qbase + (int64_t)qrow * p.ldq + d);
         }
     };
+    auto request_q = [&](int qt) { request_q_from(Qb, qt); };
+    auto q_base_of = [&](int it) { return p.Q + (int64_t)(it / p.heads) * p.q_batch_stride + (it % p.heads) * HD; };
     auto take_q = [&]() {
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) qf[ds] = (ds * 32 + g * 8 < HD) ? qnext[ds] : zero8;
@@ -244,7 +246,10 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
 #endif
     // ---- persistent walk over (sample, head) items
     int item = blockIdx.x;
-    if (item < nitems) request_kv(item, false);
+    if (item < nitems) {
+        request_kv(item, false);
+        if (wave < nqt) request_q_from(q_base_of(item), wave);   // later items: requested at the end of the previous item
+    }
     for (; item < nitems; item += gridDim.x) {
 #ifdef CGPT_STAMPS
         unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -255,7 +260,6 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
         int qt = wave;
         const bool have = qt < nqt;
-        if (have) request_q(qt);
         // K of this item: registers -> swizzled LDS image
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
@@ -297,6 +301,9 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
             qk_softmax();
             pv_store(qt);
         }
+        // this wave's first query tile of the NEXT item: a load issued only at the top of the item sat exposed in front of
+        // the first QK^T (measured with the phase stamps: ~4k of that phase's ~10k cycles)
+        if (have && item + (int)gridDim.x < nitems) request_q_from(q_base_of(item + gridDim.x), wave);
         CGPT_ASTAMP(4)                                   // remaining query tiles of this wave
         __syncthreads();                               // every wave is done with this item's LDS images
         CGPT_ASTAMP(5)                                   // waiting for the slowest wave
