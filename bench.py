@@ -98,11 +98,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CGPT_BENCH_ONE_GPU_REHEARSAL"):      # rehearse the N > 1 code path on a one-GPU box: all ranks on cuda:0, gloo
+        local = 0
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+        backend = "gloo" if os.environ.get("CGPT_BENCH_ONE_GPU_REHEARSAL") else "nccl"   # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local)
     if args.gpus != world and rank == 0 and world > 1:
