@@ -1005,6 +1005,7 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     if (force == 7) return launch_v4_epi<5>(epilogue, p, stream);
     if (force == 9) return launch_v6_epi(epilogue, 0, p, stream);
     if (force == 10) return launch_v6_epi(epilogue, 1, p, stream);
+    if (force == 11) return launch_v8_epi(epilogue, p, stream);
     if (force == 0 && p.M >= 1024) {
         // measured on MI355X (profiles/r01/gemm_variants.txt): the 256x256 direct-to-LDS tile wins on every ViT / Q-Former
         // shape, also when N is not a multiple of 256 (weights are allocated with 256-row padding); among the 256x256

@@ -31,7 +31,8 @@ struct GemmParams {
     int ablate = 0;               // measurement only: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
-hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);   // gemm6.hip: 4-wave 128x128 wave tiles
+hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);
+hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // gemm8.hip: two 4-wave workgroups per CU, 128x256 tiles   // gemm6.hip: 4-wave 128x128 wave tiles
 extern int g_gemm_ablate;
 extern int g_gemm_group_m;
 extern unsigned long long* g_gemm_dbg;

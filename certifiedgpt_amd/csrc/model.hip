@@ -675,7 +675,7 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
     if (!key) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: null key");
     const std::string k(key);
     if (k == "gemm_kernel") {
-        if (value < 0 || value > 10) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_kernel must be 0..10");
+        if (value < 0 || value > 11) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_kernel must be 0..11");
         g_gemm_kernel = value;
         return CGPT_OK;
     }

@@ -189,10 +189,11 @@ cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on);
 cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
 
 /* Process-wide tuning knobs for A/B measurements (never needed for correctness):
- *   "gemm_kernel": 0 = automatic choice; 1..10 force one GEMM kernel for A/B measurements (1 = 128x128 register-staged,
+ *   "gemm_kernel": 0 = automatic choice; 1..11 force one GEMM kernel for A/B measurements (1 = 128x128 register-staged,
  *                  2/3 = 256x256 / 256x128 direct-to-LDS, 4/5 = phase-alternating 256x256 (4 = the automatic choice for
  *                  M >= 1024), 6/7 = K=32 ring, 8 = fragments one phase ahead, 9/10 = four-wave 128x128 wave tiles with
- *                  single / paired LDS-DMA requests).  Results are identical for every choice. */
+ *                  single / paired LDS-DMA requests, 11 = two 4-wave workgroups per CU on 128x256 tiles).  Results are identical
+ *                  for every choice. */
 cgpt_status cgpt_set_option(const char* key, int32_t value);
 
 /* ---- raw kernels exported for unit tests and reuse (all fp16 operands are IEEE binary16) ----

@@ -65,7 +65,7 @@ def run_gemm(M, N, K, bias=True, seed=0, asym=False):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 192), (1, 200, 64), (257, 1408, 1408), (513, 640, 6144),
                                    (1024, 512, 128), (2000, 384, 192), (1300, 768, 1408), (1029, 256, 64)])
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_gemm_matches_fp32_reference(M, N, K, kernel):
     L = cg.lib()
     _lib.check(L.cgpt_set_option(b"gemm_kernel", kernel))
@@ -76,7 +76,7 @@ def test_gemm_matches_fp32_reference(M, N, K, kernel):
     report(f"gemm {M}x{N}x{K}", got, ref, 1e-3 + 1e-4 * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_gemm_identity_asymmetric(kernel):
     L = cg.lib()
     _lib.check(L.cgpt_set_option(b"gemm_kernel", kernel))
