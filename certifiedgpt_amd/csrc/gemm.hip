@@ -1011,6 +1011,10 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
         // shape, also when N is not a multiple of 256 (weights are allocated with 256-row padding); among the 256x256
         // schedules the phase-alternating v3 with 4 phases per K-tile is the fastest inside the model (8.17 vs 7.95 img/s
         // for v2; the 32-deep-K ring v4 is correct but slower).
+        // ... except when 256x256 tiles would leave more than half of the 256 CUs idle (the Q-Former's N = 768 linears at
+        // M = 200 x 32 rows: 75 tiles): there the 256x128 tile of v2 is 25-35 % faster (profiles/r01/gemm_variants.txt).
+        const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+        if (tiles256 <= 128 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
         return launch_v3_epi<4>(epilogue, p, stream);
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
