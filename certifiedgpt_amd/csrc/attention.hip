@@ -339,13 +339,23 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, g = lane >> 4;
     const int nqb = (p.Tq + 127) / 128;
-    const int nitems = p.heads * p.B * nqb;
     const int nchunks = (p.Tk + TKP - 1) / TKP;
     const float sl2 = p.scale * 1.44269504088896340736f;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int qb = item % nqb, h = (item / nqb) % p.heads, b = item / (nqb * p.heads);
+    // Work order: the nqb query blocks of one (sample, head) re-read the same K and V (360 KB at T = 1025).  Workgroups are
+    // dealt to the 8 XCDs round-robin by the hardware, so with a plain item = blockIdx walk every query block of a head ran
+    // on a different XCD and fetched its own copy through a different L2 (measured: HBM-bound at ~3.5 TB/s).  Here XCD x
+    // owns the (sample, head) pairs x, x+8, ... and its workgroups walk pair-major through their query blocks, so the
+    // workgroups of one XCD sit on ~4 pairs at a time and K / V come out of that XCD's L2.
+    const int npairs = p.heads * p.B;
+    const bool xcd_map = (gridDim.x & 7) == 0;
+    const int xcd = xcd_map ? (int)(blockIdx.x & 7) : 0, nx = xcd_map ? 8 : 1;
+    const int lid = xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, nl = xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int my_pairs = (npairs - xcd + nx - 1) / nx;
+    for (int w = lid; w < my_pairs * nqb; w += nl) {
+        const int pair = xcd + nx * (w / nqb), qb = w % nqb;
+        const int h = pair % p.heads, b = pair / p.heads;
         const half_t* Kg = p.K + (int64_t)b * p.kv_batch_stride + h * HD;
         const half_t* Vg = p.V + (int64_t)b * p.kv_batch_stride + h * HD;
         const half_t* Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
@@ -530,7 +540,8 @@ hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
         num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int items = p.heads * p.B * ((p.Tq + 127) / 128);
-    const int grid = items < num_cus ? items : num_cus;
+    int grid = items < num_cus ? items : num_cus;
+    if (grid >= 8) grid &= ~7;                      // a multiple of 8 enables the XCD-aware work order
     hipLaunchKernelGGL((attention_stream_kernel<HD, DPAD>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
 }
