@@ -107,16 +107,23 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(float* __restrict__ x, 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = c * 128 + l32 * 4;
-        v[c] = *reinterpret_cast<const float4*>(xr + col);
+        {
+            typedef float f32x4nt __attribute__((ext_vector_type(4)));
+            const f32x4nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(xr + col));
+            v[c] = make_float4(t[0], t[1], t[2], t[3]);
+        }
         if (delta) {
-            const f16x4 d = *reinterpret_cast<const f16x4*>(delta + rr * ldd + col);
+            const f16x4 d = __builtin_nontemporal_load(reinterpret_cast<const f16x4*>(delta + rr * ldd + col));
             v[c].x += (float)d[0]; v[c].y += (float)d[1]; v[c].z += (float)d[2]; v[c].w += (float)d[3];
         }
         if (delta2) {
-            const f16x4 d = *reinterpret_cast<const f16x4*>(delta2 + rr * ldd2 + col);
+            const f16x4 d = __builtin_nontemporal_load(reinterpret_cast<const f16x4*>(delta2 + rr * ldd2 + col));
             v[c].x += (float)d[0]; v[c].y += (float)d[1]; v[c].z += (float)d[2]; v[c].w += (float)d[3];
         }
-        if ((delta || delta2) && !keep_x && live) *reinterpret_cast<float4*>(xr + col) = v[c];
+        if ((delta || delta2) && !keep_x && live) {
+            typedef float f32x4nt __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f32x4nt{v[c].x, v[c].y, v[c].z, v[c].w}, reinterpret_cast<f32x4nt*>(xr + col));
+        }
         s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
     }
 #pragma unroll
