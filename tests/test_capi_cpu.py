@@ -130,3 +130,28 @@ def test_shard_range_partitions_exactly():
     # certify pairs the n0 range with the mirrored n range: 25 samples on every rank
     assert [(a[1] - a[0]) + (b[1] - b[0]) for a, b in ((cg.shard_range(100, r, 8), cg.shard_range(100, r, 8, mirrored=True))
                                                        for r in range(8))] == [25] * 8
+
+
+def test_scalar_statistics_against_current_scipy_on_wide_ranges():
+    """Beyond the reference-era goldens: the float64 statistics of the C-ABI against today's scipy over wide ranges (N up
+    to 10^6, alpha down to 1e-9).  SURVEY.md 8(c): scipy >= 1.12 `beta.ppf` equals statsmodels' proportion_confint("beta")
+    bit for bit on the goldens; `binomtest` differs from the removed `binom_test` only in the last digits."""
+    from scipy import stats as st
+    L = cg.lib()
+    rng = np.random.default_rng(7)
+    worst_lcb = worst_ppf = worst_bt = 0.0
+    for _ in range(400):
+        N = int(10 ** rng.uniform(0, 6)); NA = int(rng.integers(0, N + 1)); alpha = float(10 ** rng.uniform(-9, -0.7))
+        got = L.cgpt_lower_confidence_bound(NA, N, alpha)
+        ref = 0.0 if NA == 0 else float(st.beta.ppf(alpha, NA, N - NA + 1))
+        worst_lcb = max(worst_lcb, abs(got - ref) / max(ref, 1e-300) if ref > 0 else abs(got))
+        p = float(rng.uniform(1e-12, 1 - 1e-12)) if rng.random() < 0.8 else float(10 ** rng.uniform(-300, -12))
+        worst_ppf = max(worst_ppf, abs(L.cgpt_norm_ppf(p) - float(st.norm.ppf(p))) / max(1.0, abs(float(st.norm.ppf(p)))))
+    for _ in range(200):
+        n = int(10 ** rng.uniform(0, 5)); k = int(rng.integers(0, n + 1))
+        got = L.cgpt_binom_test(k, n, 0.5)
+        ref = float(st.binomtest(k, n, 0.5).pvalue)
+        worst_bt = max(worst_bt, abs(got - ref) / max(ref, 1e-300))
+    assert worst_lcb <= 1e-9, worst_lcb
+    assert worst_ppf <= 1e-12, worst_ppf
+    assert worst_bt <= 1e-9, worst_bt

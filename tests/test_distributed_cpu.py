@@ -64,7 +64,11 @@ def _many_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_certify_many_two_ranks_equals_consecutive_single_process_certify():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_certify_many_ranks_equal_consecutive_single_process_certify(world):
     ref = cg.Smooth(IndexedEngine(), K, 0.5, seed=11)
     xs = torch.zeros(3, 3, 8, 8)
     expect = [ref.certify(xs[i], 51, 77, 0.01, 16) for i in range(3)]
@@ -73,7 +77,7 @@ def test_certify_many_two_ranks_equals_consecutive_single_process_certify():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_many_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_many_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=120) for _ in procs)
