@@ -71,12 +71,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
+    constexpr int ADV = PAIR ? 2 : 1;                                   // sub-tiles per request group
     auto advance_cursor = [&]() {
-        if (ps + 1 < ns) {
-            ++ps; a_src += BK6; b_src += BK6;
+        if (ps + ADV < ns) {
+            ps += ADV; a_src += ADV * BK6; b_src += ADV * BK6;
         } else if (pt + (int)gridDim.x < ntiles) {
             pt += gridDim.x; ps = 0; set_cursor(pt);
-        }                                                               // else: stay on the last sub-tile
+        }                                                               // else: stay on the last sub-tile (pair): re-requests are harmless
     };
 
     const int rsw = ((g ^ ((0 - (r15 >> 2)) & 3)) << 3);                // swizzled chunk of this lane's fragment
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         CGPT_ROW(CA, CB, 5, Z, false, NA, nst, 0, 4, -1)                                                         \
         CGPT_ROW(CA, CB, 6, Z, false, NA, nst, 0, 5, -1)                                                         \
         CGPT_ROW(CA, CB, 7, Z, false, NA, nst, 0, 6, 7)                                                          \
-        if constexpr (req) { advance_cursor(); if constexpr (PAIR) advance_cursor(); }                           \
+        if constexpr (req) { advance_cursor(); }                           \
         ++c;                                                                                                     \
     }
 
@@ -161,9 +162,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // epilogue's bias reads out of the in-order vmcnt queue), wait for sub-tile 0, read fragment set 0
     set_cursor(pt);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < NS; s += ADV) {
 #pragma unroll
-        for (int idx = 0; idx < 8; ++idx) request_one(s, idx);
+        for (int idx = 0; idx < 8; ++idx) {
+            request_one(s, idx);
+            if constexpr (PAIR) request_one(s + 1, idx, BK6);
+        }
         advance_cursor();
     }
     float* sbias = reinterpret_cast<float*>(smem6 + NS * STAGE);
