@@ -115,6 +115,9 @@ def main():
     if os.environ.get("CGPT_GEMM_KERNEL"):          # A/B measurements only; default = the library's own choice
         from certifiedgpt_amd import _lib
         _lib.check(cg.lib().cgpt_set_option(b"gemm_kernel", int(os.environ["CGPT_GEMM_KERNEL"])))
+    if os.environ.get("CGPT_GEMM_ABLATE"):          # measurement-only switches of experimental code paths
+        from certifiedgpt_amd import _lib
+        _lib.check(cg.lib().cgpt_set_option(b"gemm_ablate", int(os.environ["CGPT_GEMM_ABLATE"])))
     dev = torch.device("cuda", local)
     # certify runs its n0 + n draws as ONE fused pass; the largest per-rank share of it is one batch
     def _share(r):

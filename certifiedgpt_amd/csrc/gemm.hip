@@ -521,10 +521,18 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                               // K-tile 0 of this tile has landed; both halves aligned
         if (late) { CGPT_SLOT_END }                    // the late half enters one slot behind
+        const int etm = tm, etn = tn;                  // this tile's coordinates (set_tile below moves on to the next tile)
+        const bool next_tile = t + (int)gridDim.x < ntiles;
+        const bool early = next_tile && !(p.ablate & 16);   // request the next tile's first K-tile during this tile's last one
 
         for (int kt = 0; kt < nk; ++kt, ++c) {
             const half_t* st = smem3 + (c & 1) * STAGE;
             const bool more = kt + 1 < nk;
+            // last K-tile: the other stage is free, so the NEXT tile's K-tile 0 is requested here, a whole K-tile before the
+            // epilogue instead of after it (it has landed by the time the epilogue is over)
+            const bool pre = !more && early;
+            if (pre) set_tile(t + gridDim.x);
+            const int nkt = pre ? 0 : kt + 1;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int ks = (NQ == 4) ? (q >> 1) : q;
@@ -539,9 +547,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < nh * HM; ++i)
                     af[h0 * HM + i] = *reinterpret_cast<const f16x8*>(st + a_rd + (h0 * HM + i) * 16 * BK + ko);
-                if (more && !(p.ablate & 1)) {
-                    if (q == 0) load_a((c + 1) & 1, kt + 1);
-                    if ((NQ == 4 && q == 1) || (NQ == 2 && q == 0)) load_b((c + 1) & 1, kt + 1);
+                if ((more || pre) && !(p.ablate & 1)) {
+                    if (q == 0) load_a((c + 1) & 1, nkt);
+                    if ((NQ == 4 && q == 1) || (NQ == 2 && q == 0)) load_b((c + 1) & 1, nkt);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (q == NQ - 1 && late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -559,10 +567,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         }
         if (!late) { CGPT_SLOT_END }                   // the early half waits one slot for its partners' last M
 
-        const int etm = tm, etn = tn;
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
-        if (t + (int)gridDim.x < ntiles) { set_tile(t + gridDim.x); load_a(c & 1, 0); load_b(c & 1, 0); }
+        if (next_tile && !early) { set_tile(t + gridDim.x); load_a(c & 1, 0); load_b(c & 1, 0); }
         gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g,
                                       (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2));
     }
