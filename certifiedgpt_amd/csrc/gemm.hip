@@ -570,8 +570,55 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
         if (next_tile && !early) { set_tile(t + gridDim.x); load_a(c & 1, 0); load_b(c & 1, 0); }
-        gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g,
-                                      (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2));
+        const bool full = (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2);
+        if ((EPI == EPI_F16 || EPI == EPI_F16_GELU) && full && (p.ldo & 7) == 0 && !(p.ablate & 512)) {
+            // fp16 output of a full tile: transposed through LDS so that a lane stores 16 contiguous bytes and 8 lanes one
+            // 128-byte line.  (Straight from the accumulators a store instruction writes 16 rows x 32 bytes: 4x the L2 write
+            // requests, 2x the store instructions; measured in the model: the stores cost 15 of the GEMMs' 97 ms per certify,
+            // 8 of them even when the target sits in L2.)  Scratch = the LDS stage of the last K-tile: every wave finished
+            // reading it before the barrier above, and the next tile does not request into it before its first barrier.
+            // Each wave owns 8 KiB of it and handles its 128 x 64 sub-tile in two passes of 64 rows; rows are 128 B, the
+            // 16-byte chunk index is XOR-swizzled with row & 7 (conflict-free ds_write_b64 / ds_read_b128).
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            half_t* scr = smem3 + ((c + 1) & 1) * STAGE + wave * 4096;
+            half_t* outp = reinterpret_cast<half_t*>(p.out);
+            // lane coordinates recomputed here (volatile: not merged with the copies the K loop uses), so that no epilogue-only
+            // value is kept -- or spilled -- across the K loop (a scratch reload would wait behind the LDS-DMA requests in flight)
+            int el;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
+            const int row_rd = el >> 3, ch_rd = el & 7, r15 = el & 15, g = el >> 4;
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = ps * 4 + ii;
+                    const int row = ii * 16 + r15;
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        f32x4 v = acc[i][jj] + bias4[jj];
+                        if constexpr (EPI == EPI_F16_GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        }
+                        const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        const int ch = (jj * 2 + (g >> 1)) ^ (row & 7);
+                        *reinterpret_cast<f16x4*>(scr + row * 64 + ch * 8 + (g & 1) * 4) = hv;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave wrote what it now reads
+                const int64_t m_base = (int64_t)etm * BM2 + wr * (BM2 / WM) + ps * 64;
+                const int n_base = etn * BN_ + wc * (BN_ / WN);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 8 + row_rd;
+                    const f16x8 o = *reinterpret_cast<const f16x8*>(scr + row * 64 + ((ch_rd ^ (row & 7)) * 8));
+                    *reinterpret_cast<f16x8*>(outp + (m_base + row) * p.ldo + n_base + ch_rd * 8) = o;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads returned before the second pass overwrites
+            }
+        } else {
+            gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g, full);
+        }
     }
 #undef CGPT_FENCE
 #undef CGPT_SLOT_END
