@@ -504,6 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
     const int nk = p.K / BK;
     int c = 0;
     int t = blockIdx.x;
+    bool lds_stores = false;
     if (t < ntiles) { set_tile(t); load_a(0, 0); load_b(0, 0); }
     for (; t < ntiles; t += gridDim.x) {
         f32x4 bias4[TN];
@@ -519,7 +520,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();                               // K-tile 0 of this tile has landed; both halves aligned
+        // K-tile 0 of this tile has landed (requested during the previous tile's last K-tile); both halves aligned.  After an
+        // LDS-path epilogue its 8 requests are older than that epilogue's 16 stores: a counted wait leaves the stores in flight
+        if (lds_stores && !(p.ablate & 1024)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CGPT_SLOT_END
         if (late) { CGPT_SLOT_END }                    // the late half enters one slot behind
         const int etm = tm, etn = tn;                  // this tile's coordinates (set_tile below moves on to the next tile)
         const bool next_tile = t + (int)gridDim.x < ntiles;
@@ -616,7 +622,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads returned before the second pass overwrites
             }
+            lds_stores = early;                        // (only then are this tile's stores younger than the next K-tile 0 requests)
         } else {
+            lds_stores = false;
             gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g, full);
         }
     }
