@@ -6,9 +6,10 @@ sigma = 0.5 through EVA-ViT-G (random-init weights of that architecture) + ln_vi
 (BASELINE.json configs[1]); i.e. n0 + n = 200 classifier forwards (reference smoothing.py:44,48).
 With N GPUs the Monte-Carlo samples of every `_sample_noise` are sharded over the ranks and the int64 vote histograms are
 summed with one RCCL all-reduce (strong scaling: the work per certified image is fixed).  The n0 selection draws and the n
-estimation draws are independent, so `certify` runs them in the same classifier batches; a rank's slice of one image is
-(n0+n)/N draws, and `Smooth.certify_many` lets the slices of N consecutive images share one 200-sample classifier batch and
-one all-reduce (same sample indices and counts as N separate `certify` calls; `config.images_per_pass`).
+estimation draws are independent, so `certify` runs them in the same classifier batches; the K images of a run go through
+`Smooth.certify_many`, which cuts the (image, sample) rows of a group of images -- on N GPUs each rank's (n0+n)/N-draw slice of
+every image -- into 255-sample classifier batches that are not aligned to image boundaries and sums all histograms of the group
+with one all-reduce (same sample indices, counts, labels and radii as K separate `certify` calls; tested).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
     (extra, NON-headline data points: --workload encode_img | rgf, --img-size 448, --n 1000 / --n0 K)
@@ -123,11 +124,14 @@ def main():
     def _share(r):
         a, b = cg.shard_range(n_sel, r, world), cg.shard_range(n_est, r, world, mirrored=True)
         return (a[1] - a[0]) + (b[1] - b[0])
-    share = max(_share(r) for r in range(world))                      # 25 at 8 GPUs (13 + 12 on every rank)
-    per_gpu = 200 if world > 1 else min(share, 200)                   # classifier batch capacity per GPU
-    # With several GPUs a rank owns only share = (n0+n)/world draws of an image; Smooth.certify_many lets the slices of
-    # `group` images share one classifier batch (and one all-reduce), so every GPU keeps running 200-sample batches.
-    group = max(1, per_gpu // share) if (world > 1 and not rgf) else 1
+    share = max(_share(r) for r in range(world))                      # draws of one image per rank: 25 at 8 GPUs (13 + 12)
+    # Classifier batch capacity.  Smooth.certify_many cuts the (image, sample) rows of a group of images into batches of this
+    # size, not aligned to image boundaries, so it is chosen for the GEMMs: 255 samples x 257 tokens = 65 535 rows = 256 tile
+    # rows of 256 -> every GEMM's tile count is a multiple of the 256 CUs (200 samples: 201 tile rows, 96 % tile efficiency).
+    per_gpu = 200 if (rgf or args.img_size != 224) else 255
+    group = 1 if rgf else 51                                          # images per certify_many call (51 x 200 = 40 x 255)
+    if os.environ.get("CGPT_BENCH_BATCH"):                            # measurement only: "capacity,group"
+        per_gpu, group = (int(v) for v in os.environ["CGPT_BENCH_BATCH"].split(","))
     clf = cg.HipClassifier(mode=mode, num_classes=NUM_CLASSES, max_batch=per_gpu, device=local, img_size=args.img_size)
     clf.init_synthetic(seed=0)                                         # identical weights on every rank
     smooth = cg.Smooth(clf, NUM_CLASSES, SIGMA, seed=42)
@@ -203,8 +207,9 @@ def main():
                        "n0": N0, "n": N, "alpha": ALPHA, "sigma": SIGMA, "num_classes": NUM_CLASSES,
                        "batch_size_per_gpu": per_gpu, "forwards_per_image": N0 + N,
                        "images_per_pass": group,
-                       "parallelism": (f"sample-sharded x{world}: every rank draws its slice of each image's n0 and n samples; "
-                                       f"{group} image(s) per fused pass, one int64[{group},2,{NUM_CLASSES}] all-reduce per pass")},
+                       "parallelism": (f"sample-sharded x{world}: every rank draws its slice of each image's n0 and n samples; up to "
+                                       f"{group} images per Smooth.certify_many call (their rows cut into {per_gpu}-sample classifier "
+                                       f"batches, one int64[G,2,{NUM_CLASSES}] all-reduce per call)")},
             "forwards_per_s": value * (N0 + N),
             "vit_tflops_end_to_end": value * (N0 + N) * F_VIT / 1e12,
             "roofline": {"bound": "mfma", "kernel": "gemm3_f16_kernel<EPI_F16_GELU, 4> (ViT MLP fc1 + GELU, M=batch*257, N=6144, K=1408)",

@@ -149,17 +149,12 @@ class HipClassifier:
     def sample_counts_images(self, xs, first_a, num_a, first_b, num_b, image_stride, sigma, seed):
         """The pair pass for several images at once (cgpt_sample_counts_images): image i draws samples
         first_a + i*image_stride + [0,num_a) and first_b + i*image_stride + [0,num_b).  Returns int64 [G, 2, num_classes];
-        identical to G sample_counts_pair calls, but floor(max_batch / (num_a+num_b)) images share a classifier batch.
-        If one image's share exceeds max_batch the images are processed one by one through sample_counts_pair."""
+        identical to G sample_counts_pair calls, but the rows of all images are cut into classifier batches of max_batch rows
+        that are not aligned to image boundaries."""
         xs = self._check_x(xs, True)
         G = xs.shape[0]
         counts = torch.zeros((G, 2, self.num_classes), dtype=torch.int64, device=xs.device)
         if num_a + num_b <= 0 or G == 0:
-            return counts
-        if num_a + num_b > self.max_batch:
-            for i in range(G):
-                counts[i] = self.sample_counts_pair(xs[i], first_a + i * image_stride, num_a, first_b + i * image_stride, num_b,
-                                                    self.max_batch, sigma, seed)
             return counts
         _lib.check(self._L.cgpt_sample_counts_images(self._h, C.c_void_p(xs.data_ptr()), G, first_a, num_a, first_b, num_b,
                                                      image_stride, C.c_void_p(counts.data_ptr()), sigma, seed, _stream_ptr()))

@@ -172,13 +172,15 @@ __global__ __launch_bounds__(256) void add_delta_kernel(float* __restrict__ x, i
 // column = c*ps*ps + (y%ps)*ps + x%ps   (= the flattening of Conv2d weight [D,3,ps,ps], eva_vit.py:202).
 // Sample index of batch row b: first_sample + b for b < na, else first_b + (b - na) (two index ranges in one batch:
 // the selection and estimation draws of Smooth.certify, smoothing.py:44,48).
-// Several images per batch (per > 0): rows are image-major, image i = b / per owns rows [i*per, (i+1)*per) with the same
-// two-range split, reads the clean image src + i*3*img*img and shifts both ranges by i*img_stride sample indices.
+// Several images (per > 0): the rows of ALL images form one image-major sequence, image i owning rows [i*per, (i+1)*per)
+// with the same two-range split; it reads the clean image src + i*3*img*img and shifts both ranges by i*img_stride sample
+// indices.  A batch is any window of that sequence: batch row b is sequence row row0 + b, so batches need not start or end
+// at image boundaries (the batch size can then be chosen for the GEMMs' tile quantisation, not for the image's draw count).
 template <bool NOISE>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ src, int img, int ps,
                                                      int64_t first_sample, int na, int64_t first_b, int nb, float sigma,
                                                      uint64_t seed, half_t* __restrict__ A, int64_t lda, int per,
-                                                     int64_t img_stride) {
+                                                     int64_t img_stride, int64_t row0) {
     const int groups = 3 * img * img / 4;                       // 4 consecutive pixels of one image row
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (int64_t)groups * nb) return;
@@ -187,7 +189,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ s
     const int c = e / (img * img), rem = e - c * img * img;
     const int y = rem / img, x0 = rem - y * img;
     // NOISE: src is the single clean image x[3,img,img]; else src is the batch [nb,3,img,img]
-    const int im = (NOISE && per > 0) ? b / per : 0, j = b - im * (per > 0 ? per : 0);
+    const int64_t rs = row0 + b;                                 // row in the sequence of all images
+    const int im = (NOISE && per > 0) ? (int)(rs / per) : 0, j = (NOISE && per > 0) ? (int)(rs - (int64_t)im * per) : b;
     float4 px = *reinterpret_cast<const float4*>(src + (NOISE ? (int64_t)im * 3 * img * img : (int64_t)b * 3 * img * img) + e);
     if (NOISE) {
         const int64_t sample = (j < na ? first_sample + j : first_b + (j - na)) + im * img_stride;
@@ -296,7 +299,7 @@ __global__ void mean_rows_kernel(const float* __restrict__ src, int64_t lds, int
 // range) or counts_b + i*2K (second range): a [images, 2, K] table when counts_b = counts + K.
 __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ logits, int64_t ld, int64_t num, int K,
                                                    unsigned long long* __restrict__ counts, int64_t na,
-                                                   unsigned long long* __restrict__ counts_b, int per) {
+                                                   unsigned long long* __restrict__ counts_b, int per, int64_t row0) {
     const int lane = threadIdx.x & 63;
     const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= num) return;
@@ -313,7 +316,8 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ log
         const int oi = __shfl_xor(bi, o);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    const int64_t im = per > 0 ? s / per : 0, j = s - im * (per > 0 ? per : 0);
+    const int64_t rs = row0 + s;
+    const int64_t im = per > 0 ? rs / per : 0, j = per > 0 ? rs - im * per : s;
     if (lane == 0) atomicAdd((j < na ? counts : counts_b) + im * 2 * K + bi, 1ull);   // rows >= na belong to the second range
 }
 
@@ -447,12 +451,12 @@ generic:
 
 hipError_t launch_noise_im2col(const float* x, int img, int ps, int64_t first_sample, int na, int64_t first_b, int nb,
                                float sigma, uint64_t seed, half_t* A, int64_t lda, hipStream_t stream, int per,
-                               int64_t img_stride) {
+                               int64_t img_stride, int64_t row0) {
     if (nb <= 0) return hipSuccess;
     if ((img & 3) || (img % ps)) return hipErrorInvalidValue;
     const int64_t n = (int64_t)nb * 3 * img * img / 4;
     hipLaunchKernelGGL(im2col_kernel<true>, dim3(blocks_for(n)), dim3(256), 0, stream, x, img, ps, first_sample, na,
-                       first_b, nb, sigma, seed, A, lda, per, img_stride);
+                       first_b, nb, sigma, seed, A, lda, per, img_stride, row0);
     return hipGetLastError();
 }
 
@@ -461,7 +465,7 @@ hipError_t launch_im2col(const float* images, int img, int ps, int nb, half_t* A
     if ((img & 3) || (img % ps)) return hipErrorInvalidValue;
     const int64_t n = (int64_t)nb * 3 * img * img / 4;
     hipLaunchKernelGGL(im2col_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, stream, images, img, ps, (int64_t)0, nb,
-                       (int64_t)0, nb, 0.0f, (uint64_t)0, A, lda, 0, (int64_t)0);
+                       (int64_t)0, nb, 0.0f, (uint64_t)0, A, lda, 0, (int64_t)0, (int64_t)0);
     return hipGetLastError();
 }
 
@@ -506,10 +510,10 @@ hipError_t launch_mean_rows(const float* src, int64_t lds, int rows, int D, int 
 }
 
 hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int64_t* counts, int64_t na, int64_t* counts_b,
-                       hipStream_t stream, int per) {
+                       hipStream_t stream, int per, int64_t row0) {
     if (num <= 0) return hipSuccess;
     hipLaunchKernelGGL(vote_kernel, dim3((unsigned)((num + 3) / 4)), dim3(256), 0, stream, logits, ld, num, K,
-                       reinterpret_cast<unsigned long long*>(counts), na, reinterpret_cast<unsigned long long*>(counts_b), per);
+                       reinterpret_cast<unsigned long long*>(counts), na, reinterpret_cast<unsigned long long*>(counts_b), per, row0);
     return hipGetLastError();
 }
 

@@ -72,7 +72,7 @@ hipError_t launch_add_delta(float* x, int64_t ldx, const half_t* delta, int64_t 
 // second), both ranges shifted by i * img_stride sample indices for image i.
 hipError_t launch_noise_im2col(const float* x, int img, int ps, int64_t first_sample, int na, int64_t first_b, int nb,
                                float sigma, uint64_t seed, half_t* A, int64_t lda, hipStream_t stream, int per = 0,
-                               int64_t img_stride = 0);
+                               int64_t img_stride = 0, int64_t row0 = 0);   // row0: sequence row of batch row 0 (per > 0)
 // Same im2col for caller-supplied images [nb,3,img,img] (no noise).
 hipError_t launch_im2col(const float* images, int img, int ps, int nb, half_t* A, int64_t lda, hipStream_t stream);
 // out[b, :] = x + sigma * eps_{first_sample + b}   (fp32 images; handle-free C-ABI cgpt_noise_batch)
@@ -96,7 +96,7 @@ hipError_t launch_mean_rows(const float* src, int64_t lds, int rows, int D, int 
 // Rows b < na vote into counts, rows b >= na into counts_b.
 // per > 0 (several images, see launch_noise_im2col): image i = row / per votes into counts + i*2K / counts_b + i*2K.
 hipError_t launch_vote(const float* logits, int64_t ld, int64_t num, int K, int64_t* counts, int64_t na, int64_t* counts_b,
-                       hipStream_t stream, int per = 0);
+                       hipStream_t stream, int per = 0, int64_t row0 = 0);
 // Smooth.certify lines 46-56 (predict = 0) or Smooth.predict lines 73-79 (predict = 1) on device histograms; one wave.
 // out[0] = label, out[1] = radius | p-value (float64).
 hipError_t launch_finalize(const int64_t* csel, const int64_t* cest, int K, int64_t n, double alpha, double sigma, int predict,

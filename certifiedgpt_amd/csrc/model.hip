@@ -319,11 +319,11 @@ cgpt_status attention(const half_t* Q, int64_t ldq, int64_t qbs, const half_t* K
 // One base-classifier forward for nb samples.  src: the clean image (noise=true) or nb images (noise=false).
 // With noise: batch row b is sample first_sample + b for b < na, first_b + (b - na) otherwise.
 cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_sample, int na, int64_t first_b, int nb,
-                    float sigma, uint64_t seed, hipStream_t st, int per = 0, int64_t img_stride = 0) {
+                    float sigma, uint64_t seed, hipStream_t st, int per = 0, int64_t img_stride = 0, int64_t row0 = 0) {
     const cgpt_config& c = m->cfg;
     const int D = m->D, Dk = m->Dk, T = m->T, P = m->P, M = nb * T;
     // K1 + im2col: smoothing.py:95-96 fused into the patch-embed operand (eva_vit.py:202,209)
-    if (noise) HIPCHK(launch_noise_im2col(src, c.img_size, c.patch_size, first_sample, na, first_b, nb, sigma, seed, m->Apatch, m->Kpatch_p, st, per, img_stride));
+    if (noise) HIPCHK(launch_noise_im2col(src, c.img_size, c.patch_size, first_sample, na, first_b, nb, sigma, seed, m->Apatch, m->Kpatch_p, st, per, img_stride, row0));
     else HIPCHK(launch_im2col(src, c.img_size, c.patch_size, nb, m->Apatch, m->Kpatch_p, st));
     // patch-embed GEMM + bias + pos_embed, scattered to token rows 1..P; CLS row = cls + pos[0]  (eva_vit.py:333-340)
     CGCHK(gemm(m, EPI_PATCH, m->Apatch, m->Kpatch_p, m->Wpatch, m->Kpatch_p, m->bpatch, m->resid, D, m->pos, D, nb * P, D,
@@ -571,19 +571,16 @@ cgpt_status cgpt_sample_counts_images(cgpt_handle h, const float* x_dev, int64_t
                                       uint64_t noise_seed, void* stream) {
     CGCHK(check_call(h, x_dev, counts_dev, num_images, "cgpt_sample_counts_images"));
     const int64_t per = num_a + num_b;
-    if (num_a < 0 || num_b < 0 || per < 1 || per > h->cfg.max_batch)
-        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_sample_counts_images: need 1 <= num_a + num_b <= max_batch");
+    if (num_a < 0 || num_b < 0 || per < 1 || per > 0x7fffffff)
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_sample_counts_images: need num_a, num_b >= 0 and num_a + num_b >= 1");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
-    const int64_t group = h->cfg.max_batch / per;                         // images per classifier batch
-    const int64_t chw = 3LL * h->cfg.img_size * h->cfg.img_size;
-    for (int64_t i0 = 0; i0 < num_images; i0 += group) {
-        const int g = (int)((num_images - i0 < group) ? (num_images - i0) : group);
-        const int nb = g * (int)per;
-        CGCHK(forward(h, x_dev + i0 * chw, true, first_a + i0 * image_stride, (int)num_a, first_b + i0 * image_stride, nb, sigma,
-                      noise_seed, st, (int)per, image_stride));
-        int64_t* c = counts_dev + i0 * 2 * h->K;
-        HIPCHK(launch_vote(h->logits, h->K, nb, h->K, c, num_a, c + h->K, st, (int)per));
+    // the rows of all images form one sequence (image-major); batches are windows of max_batch rows of it, not aligned to images
+    const int64_t total = num_images * per;
+    for (int64_t r0 = 0; r0 < total; r0 += h->cfg.max_batch) {
+        const int nb = (int)((total - r0 < h->cfg.max_batch) ? (total - r0) : h->cfg.max_batch);
+        CGCHK(forward(h, x_dev, true, first_a, (int)num_a, first_b, nb, sigma, noise_seed, st, (int)per, image_stride, r0));
+        HIPCHK(launch_vote(h->logits, h->K, nb, h->K, counts_dev, num_a, counts_dev + h->K, st, (int)per, r0));
     }
     return CGPT_OK;
 }

@@ -128,9 +128,10 @@ cgpt_status cgpt_sample_counts2(cgpt_handle h, const float* x_dev, int64_t first
 /* The same pass for SEVERAL images at once: image i (x_dev + i*3*H*W) draws samples first_a + i*image_stride + [0, num_a)
  * and first_b + i*image_stride + [0, num_b), exactly what num_images consecutive Smooth.certify calls would use with
  * image_stride = n0 + n.  counts_dev is int64 [num_images, 2, num_classes] (selection row, estimation row), ADDED into.
- * num_a + num_b <= max_batch; floor(max_batch / (num_a + num_b)) images share one classifier batch, so a rank that owns
- * only a thin slice of every image's samples (N/8 on 8 GPUs) still runs full batches.  Counts are bit-identical to the
- * per-image calls. */
+ * The (image, sample) rows of all images form one sequence that is cut into classifier batches of max_batch rows, NOT aligned
+ * to image boundaries: a rank that owns only a thin slice of every image's samples (N/8 on 8 GPUs) still runs full batches,
+ * and max_batch can be chosen for the GEMMs' tile quantisation (255 samples = 65 535 token rows = exactly 256 tile rows)
+ * rather than for n0 + n.  Counts are bit-identical to the per-image calls. */
 cgpt_status cgpt_sample_counts_images(cgpt_handle h, const float* x_dev, int64_t num_images, int64_t first_a, int64_t num_a,
                                       int64_t first_b, int64_t num_b, int64_t image_stride, int64_t* counts_dev, float sigma,
                                       uint64_t noise_seed, void* stream);
