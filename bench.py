@@ -186,7 +186,10 @@ def main():
             traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
             traffic_note = ("bytes per launch from profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                             "FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted): read %.0f MB + write %.0f MB vs "
-                            "algorithmic %.0f MB (A 145 + W 17 + out 632)" % (pm["hbm_read_bytes_corrected"] / 1e6, pm["hbm_write_bytes"] / 1e6, 794.0))
+                            "algorithmic %.0f MB (A %.0f + W %.0f + out %.0f; full %d-sample batches)" % (
+                                pm["hbm_read_bytes_corrected"] / 1e6, pm["hbm_write_bytes"] / 1e6,
+                                (per_gpu * 257 * (1408 + 6144) * 2 + 6144 * 1408 * 2) / 1e6, per_gpu * 257 * 1408 * 2 / 1e6,
+                                6144 * 1408 * 2 / 1e6, per_gpu * 257 * 6144 * 2 / 1e6, per_gpu))
     except Exception:
         pass
 

@@ -18,7 +18,7 @@ def main():
     for i, grp in enumerate(GROUPS):
         d = os.path.join(OUT, f"p{i}")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *grp, "-d", d, "-o", "r", "--output-format", "csv", "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+               sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline"]   # the default bench command (batches of 255, 255, 255, 235 samples + the 200-sample warm-up)
         with open(os.path.join(OUT, f"p{i}.log"), "w") as log:
             subprocess.run(cmd, cwd=ROOT, env=env, stdout=log, stderr=subprocess.STDOUT, check=False)
         f = glob.glob(os.path.join(d, "**", "r_counter_collection.csv"), recursive=True)
