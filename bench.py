@@ -116,6 +116,9 @@ def main():
     if os.environ.get("CGPT_GEMM_KERNEL"):          # A/B measurements only; default = the library's own choice
         from certifiedgpt_amd import _lib
         _lib.check(cg.lib().cgpt_set_option(b"gemm_kernel", int(os.environ["CGPT_GEMM_KERNEL"])))
+    if os.environ.get("CGPT_GEMM_GROUP_M"):         # measurement only: tile rows per group of the block -> tile map
+        from certifiedgpt_amd import _lib
+        _lib.check(cg.lib().cgpt_set_option(b"gemm_group_m", int(os.environ["CGPT_GEMM_GROUP_M"])))
     if os.environ.get("CGPT_GEMM_ABLATE"):          # measurement-only switches of experimental code paths
         from certifiedgpt_amd import _lib
         _lib.check(cg.lib().cgpt_set_option(b"gemm_ablate", int(os.environ["CGPT_GEMM_ABLATE"])))
