@@ -190,3 +190,29 @@ def test_vote_first_max_and_accumulates():
         cg.vote(ld, counts)                                       # accumulates
         ref = 2 * torch.bincount(torch.argmax(logits, dim=1), minlength=K)
         assert torch.equal(counts.cpu(), ref), (K, counts.cpu().tolist()[:10], ref.tolist()[:10])
+
+
+@pytest.mark.parametrize("M,N,K", [(513, 512, 128), (1300, 6144, 1408), (300, 384, 192)])
+def test_linear_gelu_epilogue_matches_exact_erf_gelu(M, N, K):
+    """cgpt_linear_f16 with the fused GELU epilogue (Mlp.fc1 + nn.GELU, eva_vit.py:59-61) against fp32 torch: exact-erf GELU of
+    the fp32 linear output, compared at fp16 output resolution."""
+    L = cg.lib()
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    A = torch.zeros(ru(M, 256), K, dtype=torch.float16); A[:M] = (torch.randn(M, K, generator=g) * 0.6).half()
+    W = torch.zeros(ru(N, 256), K, dtype=torch.float16); W[:N] = (torch.randn(N, K, generator=g) * 0.1).half()
+    b = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float16)
+    _lib.check(L.cgpt_linear_f16(P(Ad), K, P(Wd), K, P(bd), P(out), N, None, N, M, N, K, 1, stream()))
+    torch.cuda.synchronize()
+    lin = A[:M].float() @ W[:N].float().t() + b
+    ref = torch.nn.functional.gelu(lin)                       # erf form
+    got = out.cpu().float()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    tol = 1e-3 * ref.abs() + 2e-4                             # fp16 rounding (2^-11 relative) + accumulation noise
+    assert bool((err <= tol).all()), (float(err.max()), float((err / tol).max()))
+    # the negative tail, where gelu(x) is tiny (but still a normal fp16 number): resolved to fp16 precision
+    tail = (lin < -3.0) & (lin > -4.2)
+    if tail.any():
+        assert float((err[tail] / ref[tail].abs().clamp_min(1e-7)).max()) <= 3e-2
