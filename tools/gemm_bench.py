@@ -1,5 +1,5 @@
 """Raw GEMM A/B harness behind profiles/r01/gemm_variants.txt: times cgpt_linear_f16 on the ViT-G shapes for a chosen kernel
-(cgpt_set_option "gemm_kernel": 1 v1, 2/3 v2, 4/5 v3, 6/7 v4, 8 v5) and ablation flags ("gemm_ablate": 1 no in-loop loads,
+(cgpt_set_option "gemm_kernel": 1 v1, 2/3 v2, 4/5 v3, 6/7 v4, 8 v5, 9/10 v6, 11 v8) and ablation flags ("gemm_ablate": 1 no in-loop loads,
 2 no epilogue stores).  Run on the GPU box:  python tools/gemm_bench.py"""
 import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import ctypes as C, torch
