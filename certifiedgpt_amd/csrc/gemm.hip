@@ -440,6 +440,8 @@ hipError_t launch_v2_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
 // is outstanding (K-tile t+1 goes to the other stage, requested in L0/L1 of K-tile t); every wave retires its own
 // LDS-DMA (vmcnt(0)) in the segment that occupies slot 7, so after that slot's barrier K-tile t+1 is visible to all.
 // NQ = phases per K-tile: 4 (16-MFMA quadrants) or 2 (32 MFMAs = one k-step of the whole wave tile per phase).
+template <int V> struct IntTag { static constexpr int value = V; };
+
 template <int EPI, int NQ>
 __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
     constexpr int BM2 = 256, BN_ = 256, WN = 4, WM = 2;
@@ -462,9 +464,17 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
     const int lr = lane >> 3, cpos = lane & 7;
     const half_t* a_src[A_INSTR];
     const half_t* b_src[B_INSTR];
-    int tm = 0, tn = 0;
+    // N = 256 k + 128 (ViT-G: proj / fc2 1408, qkv 4224): instead of a last 256-column tile that is half padding, the last
+    // 384 columns are covered by TWO 192-column tiles (wave tile 128 x 48: TN = 3, 12 MFMAs per phase instead of 16, three
+    // B pieces per wave instead of four).  With the block -> tile order used here every workgroup gets the same number of narrow
+    // tiles when the batch fills 256 tile rows (t = b + 256 k walks tn in steps of 2 mod 6: {0,2,4} or {1,3,5} for N = 1408).
+    const bool split_n = (p.N % 256) == 128 && p.N >= 384 && !(p.ablate & 16384);
+    int tm = 0, tn = 0, ncol0 = 0;                     // tile coordinates and first column of the tile set_tile() last selected
+    bool narrow = false;                               // ... and whether it is a 192-column tile
     auto set_tile = [&](int t) {
         tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn, p.group_m);
+        narrow = split_n && tn >= tiles_n - 2;
+        ncol0 = narrow ? (tiles_n - 2) * BN_ + (tn - (tiles_n - 2)) * 192 : tn * BN_;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             const int r = wave * (BM2 / 8) + i * 8 + lr;
@@ -472,8 +482,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            const int r = wave * (BN_ / 8) + i * 8 + lr;
-            b_src[i] = p.W + (int64_t)(tn * BN_ + r) * p.ldw + ((cpos ^ ((r >> 1) & 7)) << 3);
+            const int r = wave * (narrow ? 24 : BN_ / 8) + i * 8 + lr;      // LDS row of the B image (narrow: 192 rows, 24 per wave)
+            b_src[i] = p.W + (int64_t)(ncol0 + r) * p.ldw + ((cpos ^ ((r >> 1) & 7)) << 3);
         }
     };
     auto load_a = [&](int stage, int kt) {
@@ -483,18 +493,19 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
                                              (__attribute__((address_space(3))) void*)(sa + i * 8 * BK), 16, 0, 0);
     };
-    auto load_b = [&](int stage, int kt) {
-        half_t* sb = smem3 + stage * STAGE + A_ELEMS + wave * (BN_ / 8) * BK;
+    auto load_b = [&](int stage, int kt) {             // for the tile set_tile() last selected
+        half_t* sb = smem3 + stage * STAGE + A_ELEMS + wave * (narrow ? 24 : BN_ / 8) * BK;
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(sb + i * 8 * BK), 16, 0, 0);
+            if (i < 3 || !narrow)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + kt * BK),
+                                                 (__attribute__((address_space(3))) void*)(sb + i * 8 * BK), 16, 0, 0);
     };
 
     const int sw = (r15 >> 1) & 7;
     const int k_off0 = ((g ^ sw) << 3), k_off1 = (((4 + g) ^ sw) << 3);
     const int a_rd = (wr * (BM2 / WM) + r15) * BK;
-    const int b_rd = A_ELEMS + (wc * (BN_ / WN) + r15) * BK;
+    const int b_rd_wide = A_ELEMS + (wc * (BN_ / WN) + r15) * BK, b_rd_narrow = A_ELEMS + (wc * 48 + r15) * BK;
 
     f32x4 acc[TM][TN];
     f16x8 af[TM], bf[TN];
@@ -506,12 +517,18 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
     int t = blockIdx.x;
     bool lds_stores = false;
     if (t < ntiles) { set_tile(t); load_a(0, 0); load_b(0, 0); }
-    for (; t < ntiles; t += gridDim.x) {
-        f32x4 bias4[TN];
+    // one tile; TNv = column tiles of 16 per wave (4: 256-column tile, 3: 192-column tile)
+    auto tile_body = [&](auto tnv_tag) __attribute__((always_inline)) {
+        constexpr int TNv = decltype(tnv_tag)::value;
+        constexpr bool NARROW = TNv == 3;
+        const int b_rd = NARROW ? b_rd_narrow : b_rd_wide;
+        const int wcols = NARROW ? 48 : BN_ / WN;       // columns per wave
+        const int ecol0 = ncol0;                        // first column of THIS tile (set_tile moves on during the last K-tile)
+        f32x4 bias4[TNv];
         {
-            const int nb0 = tn * BN_ + wc * (BN_ / WN) + 4 * g;
+            const int nb0 = ecol0 + wc * wcols + 4 * g;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TNv; ++j) {
                 bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (p.bias && nb0 + j * 16 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + j * 16);
             }
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TNv; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // K-tile 0 of this tile has landed (requested during the previous tile's last K-tile); both halves aligned.  After an
         // LDS-path epilogue its 8 requests are older than that epilogue's 16 stores: a counted wait leaves the stores in flight
         if (lds_stores && !(p.ablate & 1024)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -527,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         CGPT_SLOT_END
         if (late) { CGPT_SLOT_END }                    // the late half enters one slot behind
-        const int etm = tm, etn = tn;                  // this tile's coordinates (set_tile below moves on to the next tile)
+        const int etm = tm;                            // this tile's coordinates (set_tile below moves on to the next tile)
         const bool next_tile = t + (int)gridDim.x < ntiles;
         const bool early = next_tile && !(p.ablate & 16);   // request the next tile's first K-tile during this tile's last one
 
@@ -548,7 +565,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                 // ---------------- L(q): fragment reads (+ the LDS-DMA requests of the next K-tile)
                 if (NQ == 2 || q == 0 || q == 2) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + ko);
+                    for (int j = 0; j < TNv; ++j) bf[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + ko);
                 }
 #pragma unroll
                 for (int i = 0; i < nh * HM; ++i)
@@ -564,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < nh * HM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TNv; ++j)
                         acc[h0 * HM + i][j] =
                             __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[h0 * HM + i], acc[h0 * HM + i][j], 0, 0, 0);
                 if (q == NQ - 1 && !late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -574,9 +591,20 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         if (!late) { CGPT_SLOT_END }                   // the early half waits one slot for its partners' last M
 
 #pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
+        for (int j = 0; j < TNv; ++j) asm volatile("" : "+v"(bias4[j]));
         if (next_tile && !early) { set_tile(t + gridDim.x); load_a(c & 1, 0); load_b(c & 1, 0); }
-        const bool full = (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2);
+        const bool full = (etm + 1) * BM2 <= p.M && ecol0 + (NARROW ? 192 : BN_) <= p.N && !(p.ablate & 2);
+        if constexpr (NARROW) {
+            // 192-column tile: direct epilogue (8-byte stores; 24 per lane)
+            f32x4 (&acc3)[TM][4] = acc;
+            f32x4 accn[TM][3];
+#pragma unroll
+            for (int i2 = 0; i2 < TM; ++i2)
+#pragma unroll
+                for (int j2 = 0; j2 < 3; ++j2) accn[i2][j2] = acc3[i2][j2];
+            gemm_epilogue_256<EPI, TM, 3>(p, accn, bias4, etm * BM2 + wr * (BM2 / WM) + r15, ecol0 + wc * 48 + 4 * g, full);
+            lds_stores = false;
+        } else
         if (EPI == EPI_F16_GELU && full && (p.ldo & 7) == 0 && !(p.ablate & 8192)) {
             // GELU epilogue (VALU-bound): no LDS round trip; pairs of column tiles are exchanged with v_permlane16_swap, which
             // leaves a lane with 8 consecutive columns -> 16-byte stores, 64-byte segments per row.  In the model this is 1.5 %
@@ -586,7 +614,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             half_t* outp = reinterpret_cast<half_t*>(p.out);
             const int64_t m0 = (int64_t)etm * BM2 + wr * (BM2 / WM) + r15;
-            const int n0 = etn * BN_ + wc * (BN_ / WN);
+            const int n0 = ecol0 + wc * (BN_ / WN);
 #pragma unroll
             for (int i2 = 0; i2 < TM; ++i2) {
 #pragma unroll
@@ -643,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave wrote what it now reads
                 const int64_t m_base = (int64_t)etm * BM2 + wr * (BM2 / WM) + ps * 64;
-                const int n_base = etn * BN_ + wc * (BN_ / WN);
+                const int n_base = ecol0 + wc * (BN_ / WN);
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int row = it * 8 + row_rd;
@@ -655,8 +683,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
             lds_stores = early;                        // (only then are this tile's stores younger than the next K-tile 0 requests)
         } else {
             lds_stores = false;
-            gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g, full);
+            gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, ecol0 + wc * (BN_ / WN) + 4 * g, full);
         }
+    };
+    for (; t < ntiles; t += gridDim.x) {
+        if (narrow) tile_body(IntTag<3>{});
+        else tile_body(IntTag<4>{});
     }
 #undef CGPT_FENCE
 #undef CGPT_SLOT_END

@@ -194,7 +194,12 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
  *                  2/3 = 256x256 / 256x128 direct-to-LDS, 4/5 = phase-alternating 256x256 (4 = the automatic choice for
  *                  M >= 1024), 6/7 = K=32 ring, 8 = fragments one phase ahead, 9/10 = four-wave 128x128 wave tiles with
  *                  single / paired LDS-DMA requests, 11 = two 4-wave workgroups per CU on 128x256 tiles).  Results are identical
- *                  for every choice. */
+ *                  for every choice.
+ *   "gemm_ablate": bit mask of measurement switches inside the GEMM kernels (0 in production).  Bits 16 / 512 / 1024 / 8192 /
+ *                  16384 turn off one optimisation each without changing results (early request of the next tile's first
+ *                  K-tile, the LDS-transposed fp16 epilogue, the counted wait at tile start, the register-exchange GELU stores,
+ *                  the 192-column last tiles for N = 256k+128); bits 1 and 2 skip the operand loads / the epilogue and give
+ *                  WRONG results -- timing studies only (profiles/r01/gemm_variants.txt). */
 cgpt_status cgpt_set_option(const char* key, int32_t value);
 
 /* ---- raw kernels exported for unit tests and reuse (all fp16 operands are IEEE binary16) ----

@@ -192,6 +192,39 @@ def test_vote_first_max_and_accumulates():
         assert torch.equal(counts.cpu(), ref), (K, counts.cpu().tolist()[:10], ref.tolist()[:10])
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 384, 192), (1500, 640, 128), (2313, 1408, 1408), (1028, 4224, 256)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_linear_split_last_columns_is_bit_identical(M, N, K, epi):
+    """N = 256 k + 128 (ViT-G: 1408, 4224): the GEMM covers the last 384 columns with two 192-column tiles instead of one full
+    and one half-empty 256-column tile.  The accumulation order per output element is unchanged, so every epilogue must give
+    the same bits as the unsplit tiling (gemm_ablate bit 16384) -- and untouched memory outside [M, N] stays untouched."""
+    L = cg.lib()
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + epi)
+    A = torch.zeros(ru(M, 256), K, dtype=torch.float16); A[:M] = (torch.randn(M, K, generator=g) * 0.5).half()
+    W = torch.zeros(ru(N, 256), K, dtype=torch.float16); W[:N] = (torch.randn(N, K, generator=g) * 0.1).half()
+    b = torch.randn(N, generator=g)
+    aux = torch.randn(M, N + 8, generator=g).to(DEV) if epi == 3 else None
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    outs = []
+    try:
+        for abl in (16384, 0):
+            out = torch.full((M + 1, N + 8), 7.0, device=DEV, dtype=torch.float16 if epi < 2 else torch.float32)
+            _lib.check(L.cgpt_set_option(b"gemm_ablate", abl))
+            _lib.check(L.cgpt_linear_f16(P(Ad), K, P(Wd), K, P(bd), P(out), N + 8, P(aux) if aux is not None else None, N + 8, M, N, K, epi, stream()))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        _lib.check(L.cgpt_set_option(b"gemm_ablate", 0))
+    assert torch.equal(outs[0], outs[1])
+    assert bool((outs[1][:, N:] == 7.0).all()) and bool((outs[1][M] == 7.0).all())
+    ref = A[:M].float() @ W[:N].float().t() + b
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 3:
+        ref = ref + aux[:, :N].cpu()
+    report(f"linear split {M}x{N}x{K} epi{epi}", outs[1][:M, :N].float().cpu(), ref, 2e-3 + 1e-3 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K", [(513, 512, 128), (1300, 6144, 1408), (300, 384, 192)])
 def test_linear_gelu_epilogue_matches_exact_erf_gelu(M, N, K):
     """cgpt_linear_f16 with the fused GELU epilogue (Mlp.fc1 + nn.GELU, eva_vit.py:59-61) against fp32 torch: exact-erf GELU of
