@@ -594,18 +594,19 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         for (int j = 0; j < TNv; ++j) asm volatile("" : "+v"(bias4[j]));
         if (next_tile && !early) { set_tile(t + gridDim.x); load_a(c & 1, 0); load_b(c & 1, 0); }
         const bool full = (etm + 1) * BM2 <= p.M && ecol0 + (NARROW ? 192 : BN_) <= p.N && !(p.ablate & 2);
-        if constexpr (NARROW) {
-            // 192-column tile: direct epilogue (8-byte stores; 24 per lane)
-            f32x4 (&acc3)[TM][4] = acc;
-            f32x4 accn[TM][3];
+        constexpr bool F16_OUT = EPI == EPI_F16 || EPI == EPI_F16_GELU;
+        if (NARROW && !(F16_OUT && full && (p.ldo & 7) == 0 && !(p.ablate & 512))) {
+            // 192-column tile, fp32 / patch-embed / partial: direct epilogue
+            if constexpr (NARROW) {
+                f32x4 accn[TM][3];
 #pragma unroll
-            for (int i2 = 0; i2 < TM; ++i2)
+                for (int i2 = 0; i2 < TM; ++i2)
 #pragma unroll
-                for (int j2 = 0; j2 < 3; ++j2) accn[i2][j2] = acc3[i2][j2];
-            gemm_epilogue_256<EPI, TM, 3>(p, accn, bias4, etm * BM2 + wr * (BM2 / WM) + r15, ecol0 + wc * 48 + 4 * g, full);
+                    for (int j2 = 0; j2 < 3; ++j2) accn[i2][j2] = acc[i2][j2];
+                gemm_epilogue_256<EPI, TM, 3>(p, accn, bias4, etm * BM2 + wr * (BM2 / WM) + r15, ecol0 + wc * 48 + 4 * g, full);
+            }
             lds_stores = false;
-        } else
-        if (EPI == EPI_F16_GELU && full && (p.ldo & 7) == 0 && !(p.ablate & 8192)) {
+        } else if (!NARROW && EPI == EPI_F16_GELU && full && (p.ldo & 7) == 0 && !(p.ablate & 8192)) {
             // GELU epilogue (VALU-bound): no LDS round trip; pairs of column tiles are exchanged with v_permlane16_swap, which
             // leaves a lane with 8 consecutive columns -> 16-byte stores, 64-byte segments per row.  In the model this is 1.5 %
             // faster for fc1 than the LDS path below, which wins (by 1 %) for the plain fp16 epilogues.
@@ -635,14 +636,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                 }
             }
             lds_stores = early;
-        } else if ((EPI == EPI_F16 || EPI == EPI_F16_GELU) && full && (p.ldo & 7) == 0 && !(p.ablate & 512)) {
+        } else if (F16_OUT && full && (p.ldo & 7) == 0 && !(p.ablate & 512)) {
             // fp16 output of a full tile: transposed through LDS so that a lane stores 16 contiguous bytes and 8 lanes one
             // 128-byte line.  (Straight from the accumulators a store instruction writes 16 rows x 32 bytes: 4x the L2 write
             // requests, 2x the store instructions; measured in the model: the stores cost 15 of the GEMMs' 97 ms per certify,
             // 8 of them even when the target sits in L2.)  Scratch = the LDS stage of the last K-tile: every wave finished
             // reading it before the barrier above, and the next tile does not request into it before its first barrier.
             // Each wave owns 8 KiB of it and handles its 128 x 64 sub-tile in two passes of 64 rows; rows are 128 B, the
-            // 16-byte chunk index is XOR-swizzled with row & 7 (conflict-free ds_write_b64 / ds_read_b128).
+            // 16-byte chunk index is XOR-swizzled with row & 7 (conflict-free ds_write_b64 / ds_read_b128).  A 192-column tile
+            // uses 6 of a row's 8 chunks (128 x 48 per wave): the read / store instructions run with 48 of 64 lanes.
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             half_t* scr = smem3 + ((c + 1) & 1) * STAGE + wave * 4096;
             half_t* outp = reinterpret_cast<half_t*>(p.out);
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                     const int i = ps * 4 + ii;
                     const int row = ii * 16 + r15;
 #pragma unroll
-                    for (int jj = 0; jj < TN; ++jj) {
+                    for (int jj = 0; jj < TNv; ++jj) {
                         f32x4 v = acc[i][jj] + bias4[jj];
                         if constexpr (EPI == EPI_F16_GELU) {
 #pragma unroll
@@ -671,19 +673,22 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave wrote what it now reads
                 const int64_t m_base = (int64_t)etm * BM2 + wr * (BM2 / WM) + ps * 64;
-                const int n_base = ecol0 + wc * (BN_ / WN);
+                const int n_base = ecol0 + wc * wcols;
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int row = it * 8 + row_rd;
-                    const f16x8 o = *reinterpret_cast<const f16x8*>(scr + row * 64 + ((ch_rd ^ (row & 7)) * 8));
-                    *reinterpret_cast<f16x8*>(outp + (m_base + row) * p.ldo + n_base + ch_rd * 8) = o;
+                    if (!NARROW || ch_rd < 6) {
+                        const f16x8 o = *reinterpret_cast<const f16x8*>(scr + row * 64 + ((ch_rd ^ (row & 7)) * 8));
+                        *reinterpret_cast<f16x8*>(outp + (m_base + row) * p.ldo + n_base + ch_rd * 8) = o;
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads returned before the second pass overwrites
             }
             lds_stores = early;                        // (only then are this tile's stores younger than the next K-tile 0 requests)
         } else {
             lds_stores = false;
-            gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, ecol0 + wc * (BN_ / WN) + 4 * g, full);
+            if constexpr (!NARROW)
+                gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, ecol0 + wc * (BN_ / WN) + 4 * g, full);
         }
     };
     for (; t < ntiles; t += gridDim.x) {
