@@ -198,7 +198,7 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
  *   "gemm_ablate": bit mask of measurement switches inside the GEMM kernels (0 in production).  Bits 16 / 512 / 1024 / 8192 /
  *                  16384 turn off one optimisation each without changing results (early request of the next tile's first
  *                  K-tile, the LDS-transposed fp16 epilogue, the counted wait at tile start, the register-exchange GELU stores,
- *                  the 192-column last tiles for N = 256k+128); bits 1, 2 and 4 skip the operand loads / the epilogue / the fp16 stores and give
+ *                  the 192-column last tiles for N = 256k+128); bits 1 and 2 skip the operand loads / the epilogue and give
  *                  WRONG results -- timing studies only (profiles/r01/gemm_variants.txt). */
 cgpt_status cgpt_set_option(const char* key, int32_t value);
 
