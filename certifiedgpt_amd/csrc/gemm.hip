@@ -524,6 +524,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
     int c = 0;
     int t = blockIdx.x;
     bool lds_stores = false;
+#ifdef CGPT_STAMPS
+    unsigned long long st_wait = 0, st_loop = 0, st_epi = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
     if (t < ntiles) { set_tile(t); load_a(0, 0); load_b(0, 0); }
     // one tile; TNv = column tiles of 16 per wave (4: 256-column tile, 3: 192-column tile)
     auto tile_body = [&](auto tnv_tag) __attribute__((always_inline)) {
@@ -545,6 +549,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TNv; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef CGPT_STAMPS
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
         // K-tile 0 of this tile has landed (requested during the previous tile's last K-tile); both halves aligned.  After an
         // LDS-path epilogue its 8 requests are older than that epilogue's 16 stores: a counted wait leaves the stores in flight
         if (lds_stores && !(p.ablate & 1024)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -552,6 +559,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         CGPT_SLOT_END
         if (late) { CGPT_SLOT_END }                    // the late half enters one slot behind
+#ifdef CGPT_STAMPS
+        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
         const int etm = tm;                            // this tile's coordinates (set_tile below moves on to the next tile)
         const bool next_tile = t + (int)gridDim.x < ntiles;
         const bool early = next_tile && !(p.ablate & 16);   // request the next tile's first K-tile during this tile's last one
@@ -597,6 +607,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
             }
         }
         if (!late) { CGPT_SLOT_END }                   // the early half waits one slot for its partners' last M
+#ifdef CGPT_STAMPS
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
 
 #pragma unroll
         for (int j = 0; j < TNv; ++j) asm volatile("" : "+v"(bias4[j]));
@@ -701,11 +714,20 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
             if constexpr (!NARROW)
                 gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, ecol0 + wc * (BN_ / WN) + 4 * g, full);
         }
+#ifdef CGPT_STAMPS
+        st_wait += ts1 - ts0; st_loop += ts2 - ts1; st_epi += __builtin_amdgcn_s_memtime() - ts2;
+#endif
     };
     for (; t < ntiles; t += gridDim.x) {
         if (narrow) tile_body(IntTag<3>{});
         else tile_body(IntTag<4>{});
     }
+#ifdef CGPT_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+        d[0] = __builtin_amdgcn_s_memtime() - st_begin; d[1] = st_wait; d[2] = st_loop; d[3] = st_epi;
+    }
+#endif
 #undef CGPT_FENCE
 #undef CGPT_SLOT_END
 }
