@@ -347,8 +347,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
         if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n);
         if constexpr (EPI == EPI_F16 || EPI == EPI_F16_GELU) {
             if constexpr (EPI == EPI_F16_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                v = gelu_erf4(v);
             }
             const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             *reinterpret_cast<f16x4*>(reinterpret_cast<half_t*>(p.out) + orow + n) = hv;
@@ -627,10 +626,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                 gemm_epilogue_256<EPI, TM, 3>(p, accn, bias4, etm * BM2 + wr * (BM2 / WM) + r15, ecol0 + wc * 48 + 4 * g, full);
             }
             lds_stores = false;
-        } else if (!NARROW && EPI == EPI_F16_GELU && full && (p.ldo & 7) == 0 && !(p.ablate & 8192)) {
-            // GELU epilogue (VALU-bound): no LDS round trip; pairs of column tiles are exchanged with v_permlane16_swap, which
-            // leaves a lane with 8 consecutive columns -> 16-byte stores, 64-byte segments per row.  In the model this is 1.5 %
-            // faster for fc1 than the LDS path below, which wins (by 1 %) for the plain fp16 epilogues.
+        } else if (!NARROW && EPI == EPI_F16_GELU && full && (p.ldo & 7) == 0 && (p.ablate & 8192)) {
+            // ALTERNATIVE GELU epilogue, kept for A/B runs (gemm_ablate bit 8192): no LDS round trip; pairs of column tiles are
+            // exchanged with v_permlane16_swap, which leaves a lane with 8 consecutive columns -> 16-byte stores, 64-byte
+            // segments per row.  With plain stores it was 1.5 % faster for fc1 than the LDS path below; with nontemporal stores
+            // the LDS path's full 128-byte lines win by 1.5 % (64-byte streamed segments: 31 % more HBM write traffic, PMC).
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -686,8 +686,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                     for (int jj = 0; jj < TNv; ++jj) {
                         f32x4 v = acc[i][jj] + bias4[jj];
                         if constexpr (EPI == EPI_F16_GELU) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                            v = gelu_erf4(v);
                         }
                         const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                         const int ch = (jj * 2 + (g >> 1)) ^ (row & 7);

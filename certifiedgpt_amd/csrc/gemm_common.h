@@ -61,7 +61,11 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     r = r * r;
     r = r * r;
     r = r * r;
-    return f32x2{fmaf(u[0], r[0], fmaxf(x[0], 0.0f)), fmaf(u[1], r[1], fmaxf(x[1], 0.0f))};
+    return __builtin_elementwise_fma(u, r, f32x2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)});
+}
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
+    const f32x2 a = gelu_erf2(f32x2{v[0], v[1]}), b = gelu_erf2(f32x2{v[2], v[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
 }
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float v) {
@@ -130,8 +134,7 @@ __device__ __forceinline__ void gemm_epilogue_256(const GemmParams& p, f32x4 (&a
         if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n);
         if constexpr (EPI == EPI_F16 || EPI == EPI_F16_GELU) {
             if constexpr (EPI == EPI_F16_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                v = gelu_erf4(v);
             }
             const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             *reinterpret_cast<f16x4*>(reinterpret_cast<half_t*>(p.out) + orow + n) = hv;

@@ -195,10 +195,11 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
  *                  M >= 1024), 6/7 = K=32 ring, 8 = fragments one phase ahead, 9/10 = four-wave 128x128 wave tiles with
  *                  single / paired LDS-DMA requests, 11 = two 4-wave workgroups per CU on 128x256 tiles).  Results are identical
  *                  for every choice.
- *   "gemm_ablate": bit mask of measurement switches inside the GEMM kernels (0 in production).  Bits 16 / 512 / 1024 / 8192 /
+ *   "gemm_ablate": bit mask of measurement switches inside the GEMM kernels (0 in production).  Bits 16 / 512 / 1024 /
  *                  16384 turn off one optimisation each without changing results (early request of the next tile's first
- *                  K-tile, the LDS-transposed fp16 epilogue, the counted wait at tile start, the register-exchange GELU stores,
- *                  the 192-column last tiles for N = 256k+128); bits 1 and 2 skip the operand loads / the epilogue and give
+ *                  K-tile, the LDS-transposed fp16 epilogue, the counted wait at tile start, the 192-column last tiles for
+ *                  N = 256k+128), bit 8192 selects the register-exchange variant of the GELU epilogue (same results);
+ *                  bits 1 and 2 skip the operand loads / the epilogue and give
  *                  WRONG results -- timing studies only (profiles/r01/gemm_variants.txt). */
 cgpt_status cgpt_set_option(const char* key, int32_t value);
 
