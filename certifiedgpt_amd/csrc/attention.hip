@@ -77,15 +77,18 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
     // V of the current item right after its K has gone to LDS (it lands under the first QK^T + softmax).
     f16x8 sreg[NV];
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (uniform 64-bit base + 32-bit lane offset: the same NV offsets serve K and V -- launch_attention checks ldk == ldv -- and
+    // take half the registers of per-lane pointers, which the compiler used to spill: a scratch reload in front of a request
+    // waits for EVERY load in flight, e.g. for the V loads issued just before the first QK^T)
     auto request_kv = [&](int item, bool want_v) {
         const int hh = item % p.heads, bb = item / p.heads;
         const half_t* G = (want_v ? p.V : p.K) + (int64_t)bb * p.kv_batch_stride + hh * HD;
-        const int64_t ldg = want_v ? p.ldv : p.ldk;
+        const int ldg = (int)p.ldk;
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int idx = tid + it * NT;
             const int row = min(idx / CH, p.Tk - 1), ch = min(idx % CH, HD / 8 - 1);
-            sreg[it] = *reinterpret_cast<const f16x8*>(G + (int64_t)row * ldg + ch * 8);
+            sreg[it] = *reinterpret_cast<const f16x8*>(G + (row * ldg + ch * 8));
         }
     };
 
@@ -99,11 +102,13 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
     f16x8 qf[NDS], qnext[NDS];
     // Q^T B-fragments of query tile qt: lane holds Q[query r15][d = 32*ds + 8*g .. +7] (zero beyond HD)
     auto request_q_from = [&](const half_t* qbase, int qt) {
-        const int qrow = min(qt * 16 + r15, p.Tq - 1);
+        int el;                                        // lane id recomputed (volatile): no per-lane address lives across the item loop
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
+        const int qoff = min(qt * 16 + (el & 15), p.Tq - 1) * (int)p.ldq;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
-            const int d = min(ds * 32 + g * 8, HD - 8);
-            qnext[ds] = *reinterpret_cast<const f16x8*>(qbase + (int64_t)qrow * p.ldq + d);
+            const int d = min(ds * 32 + (el >> 4) * 8, HD - 8);
+            qnext[ds] = *reinterpret_cast<const f16x8*>(qbase + (qoff + d));
         }
     };
     auto request_q = [&](int qt) { request_q_from(Qb, qt); };
@@ -280,9 +285,16 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         CGPT_ASTAMP(0)                                   // K -> LDS + barrier
         request_kv(item, true);                          // V of this item; lands under the first QK^T + softmax
         // first query tile of every wave: QK^T + softmax run before V is needed in LDS
+        // after a wave has taken its LAST query tile of this item it requests its first tile of the NEXT item: a whole tile of
+        // lead (issued at the top of the item the load sat exposed in front of the first QK^T: ~4k of that phase's ~10k cycles)
+        const bool more_items = item + (int)gridDim.x < nitems;
+        auto request_following = [&](int cur) {
+            if (cur + NWAVES < nqt) request_q(cur + NWAVES);
+            else if (more_items) request_q_from(q_base_of(item + gridDim.x), wave);
+        };
         if (have) {
             take_q();
-            if (qt + NWAVES < nqt) request_q(qt + NWAVES);
+            request_following(qt);
             qk_softmax();
         }
         CGPT_ASTAMP(1)                                   // first QK^T + softmax
@@ -305,13 +317,10 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         CGPT_ASTAMP(3)                                   // first P.V + store
         for (qt += NWAVES; qt < nqt; qt += NWAVES) {
             take_q();
-            if (qt + NWAVES < nqt) request_q(qt + NWAVES);
+            request_following(qt);
             qk_softmax();
             pv_store(qt);
         }
-        // this wave's first query tile of the NEXT item: a load issued only at the top of the item sat exposed in front of
-        // the first QK^T (measured with the phase stamps: ~4k of that phase's ~10k cycles)
-        if (have && item + (int)gridDim.x < nitems) request_q_from(q_base_of(item + gridDim.x), wave);
         CGPT_ASTAMP(4)                                   // remaining query tiles of this wave
         __syncthreads();                               // every wave is done with this item's LDS images
         CGPT_ASTAMP(5)                                   // waiting for the slowest wave
@@ -591,6 +600,7 @@ hipError_t launch_attention(const AttnParams& p_in, hipStream_t stream) {
     p.dbg = g_gemm_dbg;                             // diagnostic stamp buffer (null outside -DCGPT_STAMPS experiments)
     if (p.B <= 0 || p.heads <= 0 || p.Tq <= 0 || p.Tk <= 0) return hipErrorInvalidValue;
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 8)) return hipErrorInvalidValue;   // 16-byte row alignment
+    if (p.ldk != p.ldv || p.Tk * p.ldk >= (1ll << 30) || p.Tq * p.ldq >= (1ll << 30)) return hipErrorInvalidValue;   // 32-bit offsets within a sample
     const bool small = p.Tk <= 32;
     if (p.Tk > 288) {                               // K/V streamed through LDS in 288-key chunks (448^2 images)
         if (p.head_dim == 88) return launch_stream<88, 96>(p, stream);
