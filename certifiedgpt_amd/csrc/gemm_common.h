@@ -20,8 +20,8 @@ constexpr int GROUP_M = 8;
 // -- the form of Abramowitz-Stegun 7.1.28 (one reciprocal and four squarings instead of exp AND reciprocal), degree 7, coefficients
 // fitted for |x| * error, i.e. the error of GELU itself: <= 6e-8 in exact arithmetic, <= 3.6e-7 evaluated in fp32, 0.1 % relative in
 // the tail -4.2 < x < -3 (fp16 output resolution is 5e-4 relative).  (A&S 7.1.26, used before: 3.3e-7 / 0.06 %, two transcendentals.)
-// gelu_erf2 is the SAME arithmetic on two values with v_pk_fma_f32 / v_pk_mul_f32 (IEEE per component): bit-identical to gelu_erf,
-// so every epilogue path gives a value that depends on nothing but the element.  Per element: 48 issue cycles instead of 76.
+// gelu_erf2 evaluates two values with v_pk_fma_f32 / v_pk_mul_f32 (IEEE per component); every epilogue path goes through it, so a
+// value depends on nothing but the element.  Per element: 42 issue cycles instead of 58.
 #define CGPT_GELU_C1 -0.09973713755607605f
 #define CGPT_GELU_C2 0.08452103286981583f
 #define CGPT_GELU_C3 -0.026464305818080902f
@@ -29,22 +29,6 @@ constexpr int GROUP_M = 8;
 #define CGPT_GELU_C5 -0.002318566432222724f
 #define CGPT_GELU_C6 -9.743619011715055e-05f
 #define CGPT_GELU_C7 -9.806572779780254e-05f
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float u = fabsf(x) * -0.5f;
-    float q = fmaf(u, CGPT_GELU_C7, CGPT_GELU_C6);
-    q = fmaf(q, u, CGPT_GELU_C5);
-    q = fmaf(q, u, CGPT_GELU_C4);
-    q = fmaf(q, u, CGPT_GELU_C3);
-    q = fmaf(q, u, CGPT_GELU_C2);
-    q = fmaf(q, u, CGPT_GELU_C1);
-    q = fmaf(q, u, 1.0f);
-    float r = __builtin_amdgcn_rcpf(q);
-    r = r * r;
-    r = r * r;
-    r = r * r;
-    r = r * r;                                                                       // q^-16 = 2 (1 - Phi(|x|))
-    return fmaf(u, r, fmaxf(x, 0.0f));                                               // x>=0: x - |x| h ; x<0: -|x| h
-}
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     const f32x2 u = {fabsf(x[0]) * -0.5f, fabsf(x[1]) * -0.5f};
@@ -62,6 +46,14 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     r = r * r;
     r = r * r;
     return __builtin_elementwise_fma(u, r, f32x2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)});
+}
+// One value: the same arithmetic, result rounded to fp32 before anything else happens to it.  A plain fmaf version is not bit-identical
+// once its result is converted to fp16: the compiler fuses the last fma with the conversion (v_fma_mix: one rounding), the packed
+// path rounds to fp32 first and converts afterwards -- 6 of 192 000 outputs differed by one fp16 ulp.
+__device__ __forceinline__ float gelu_erf(float x) {
+    float r = gelu_erf2(f32x2{x, x})[0];
+    asm volatile("" : "+v"(r));                          // the fp32 result is materialised before any conversion
+    return r;
 }
 __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
     const f32x2 a = gelu_erf2(f32x2{v[0], v[1]}), b = gelu_erf2(f32x2{v[2], v[3]});

@@ -225,6 +225,41 @@ def test_linear_split_last_columns_is_bit_identical(M, N, K, epi):
     report(f"linear split {M}x{N}x{K} epi{epi}", outs[1][:M, :N].float().cpu(), ref, 2e-3 + 1e-3 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("epi", [0, 1])
+def test_fp16_epilogue_value_does_not_depend_on_kernel_or_tile_path(epi):
+    """The same rows through (a) a small launch (M = 300: another kernel, guarded per-element epilogue with the scalar GELU) and
+    (b) a large one (M = 1300: 256x256 tiles, full tiles with the packed-fp32 GELU, the last tile row partial) must agree bit for
+    bit (a fused fma+convert in one path and fma, then convert in the other differ by one fp16 ulp in 3 of 100 000 values): the counts of Smooth.certify may not depend on how the samples were cut into batches (smoothing.py:91-98)."""
+    L = cg.lib()
+    N, K = 640, 256
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.zeros(ru(1300, 256), K, dtype=torch.float16); A[:1300] = (torch.randn(1300, K, generator=g) * 0.7).half()
+    W = torch.zeros(ru(N, 256), K, dtype=torch.float16); W[:N] = (torch.randn(N, K, generator=g) * 0.15).half()
+    b = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    outs = []
+    for M in (300, 1300):
+        out = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+        _lib.check(L.cgpt_linear_f16(P(Ad), K, P(Wd), K, P(bd), P(out), N, None, N, M, N, K, epi, stream()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1][:300])
+    try:                                                     # ... and every forced kernel on the small launch
+        for kernel in (1, 2, 4):
+            _lib.check(L.cgpt_set_option(b"gemm_kernel", kernel))
+            out = torch.zeros(300, N, device=DEV, dtype=torch.float16)
+            _lib.check(L.cgpt_linear_f16(P(Ad), K, P(Wd), K, P(bd), P(out), N, None, N, 300, N, K, epi, stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(out, outs[0]), kernel
+    finally:
+        _lib.check(L.cgpt_set_option(b"gemm_kernel", 0))
+    # the partial last tile row of the large launch (guarded path) against the same rows inside full tiles of a third launch
+    out3 = torch.zeros(1536, N, device=DEV, dtype=torch.float16)
+    _lib.check(L.cgpt_linear_f16(P(Ad), K, P(Wd), K, P(bd), P(out3), N, None, N, 1536, N, K, epi, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], out3[:1300])
+
+
 @pytest.mark.parametrize("M,N,K", [(513, 512, 128), (1300, 6144, 1408), (300, 384, 192)])
 def test_linear_gelu_epilogue_matches_exact_erf_gelu(M, N, K):
     """cgpt_linear_f16 with the fused GELU epilogue (Mlp.fc1 + nn.GELU, eva_vit.py:59-61) against fp32 torch: exact-erf GELU of
