@@ -426,7 +426,7 @@ hipError_t launch_v2_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
 
 // ------------------------------------------------------------------------------------------------ v3
 // Same tile, staging and swizzle as v2<256>, different time structure (the "phase" structure of the MI355X guide):
-// measured on v2 (in-kernel s_memtime stamps, profiles/r01/gemm_v2_stamps.txt) the OLDER wave of every SIMD wins MFMA
+// measured on v2 (in-kernel s_memtime stamps, profiles/r01/gemm_variants.txt) the OLDER wave of every SIMD wins MFMA
 // arbitration, finishes its K-tile early and parks 25 % of its time at the barrier, after which the younger wave runs
 // alone with its 8 LDS-DMA issues (40-70 cycles each) and 24 fragment reads exposed.  Here the two waves of a SIMD
 // (w and w+4 = the top / bottom 128 rows of the tile) execute the same program ONE SLOT apart:
