@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
 // 16-byte variant for D % 128 == 0: one row per HALF-wave (32 lanes x NCH float4), two rows per wave; the row still lives
 // in registers between the three passes.  Wider accesses than the float2 kernel (16 B per lane instead of 8 B).
 template <int NCH>
-__global__ __launch_bounds__(256) void layernorm4_kernel(float* __restrict__ x, int64_t ldx,
+__device__ __forceinline__ void layernorm4_body(float* __restrict__ x, int64_t ldx,
                                                          const half_t* __restrict__ delta, int64_t ldd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, half_t* __restrict__ y16, int64_t ldy16,
@@ -149,6 +149,18 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(float* __restrict__ x, 
         if (y16) *reinterpret_cast<f16x4*>(y16 + row * ldy16 + col) = f16x4{(half_t)o0, (half_t)o1, (half_t)o2, (half_t)o3};
         if (y32) *reinterpret_cast<float4*>(y32 + row * ldy32 + col) = make_float4(o0, o1, o2, o3);
     }
+}
+
+#define CGPT_LN4_ARGS float* __restrict__ x, int64_t ldx, const half_t* __restrict__ delta, int64_t ldd, const float* __restrict__ gamma, \
+                      const float* __restrict__ beta, float eps, half_t* __restrict__ y16, int64_t ldy16, float* __restrict__ y32, \
+                      int64_t ldy32, int64_t rows, int D, const half_t* __restrict__ delta2, int64_t ldd2, int keep_x
+#define CGPT_LN4_PASS x, ldx, delta, ldd, gamma, beta, eps, y16, ldy16, y32, ldy32, rows, D, delta2, ldd2, keep_x
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm4_kernel(CGPT_LN4_ARGS) { layernorm4_body<NCH>(CGPT_LN4_PASS); }
+// The ViT-G width (D = 1408, NCH = 11) with amdgpu_waves_per_eu(6, 8): 80 instead of 86 VGPRs, six waves per SIMD instead of five:
+// 187 -> 181 us per launch in the model (7: 72 VGPRs with 2 spilled, no further gain; 8: 64 VGPRs, 6 spilled, slower).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void layernorm4_vitg_kernel(CGPT_LN4_ARGS) {
+    layernorm4_body<11>(CGPT_LN4_PASS);
 }
 
 // x[row, :] += delta[row, :]  (the last block's pending residual update, when no LayerNorm follows on those rows)
@@ -430,7 +442,8 @@ hipError_t launch_layernorm(float* x, int64_t ldx, const half_t* delta, int64_t 
         const int n = D / 128;
         if (n <= 1) CGPT_LN4(1);
         else if (n <= 6) { if (n == 6) CGPT_LN4(6); else goto generic; }
-        else if (n == 11) CGPT_LN4(11);
+        else if (n == 11) hipLaunchKernelGGL(layernorm4_vitg_kernel, grid4, block4, 0, stream, x, ldx, delta, ldd, gamma, beta, eps,
+                                             y16, ldy16, y32, ldy32, rows, D, delta2, ldd2, keep_x);
         else if (n == 32) CGPT_LN4(32);
         else goto generic;
 #undef CGPT_LN4
