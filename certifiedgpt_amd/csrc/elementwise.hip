@@ -165,11 +165,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 
 // x[row, :] += delta[row, :]  (the last block's pending residual update, when no LayerNorm follows on those rows)
 __global__ __launch_bounds__(256) void add_delta_kernel(float* __restrict__ x, int64_t ldx, const half_t* __restrict__ delta,
-                                                        int64_t ldd, int64_t rows, int D) {
+                                                        int64_t ldd, int64_t rows, int D, int skip_mod) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one float2 per thread
     const int half_d = D >> 1;
     if (i >= rows * half_d) return;
     const int64_t r = i / half_d;
+    if (skip_mod > 0 && r % skip_mod == 0) return;                           // rows already updated (the CLS rows)
     const int col = (int)(i - r * half_d) * 2;
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     float2 v = *reinterpret_cast<const float2*>(x + r * ldx + col);
@@ -188,41 +189,62 @@ __global__ __launch_bounds__(256) void add_delta_kernel(float* __restrict__ x, i
 // with the same two-range split; it reads the clean image src + i*3*img*img and shifts both ranges by i*img_stride sample
 // indices.  A batch is any window of that sequence: batch row b is sequence row row0 + b, so batches need not start or end
 // at image boundaries (the batch size can then be chosen for the GEMMs' tile quantisation, not for the image's draw count).
+// One workgroup per (batch row b, patch row py): it reads the 3 x ps image rows of that patch row with coalesced float4
+// loads, adds the noise, and stages the fp16 values of the img/ps patches in LDS as [patch][c*ps*ps + iy*ps + ix]; every
+// patch row of A (3*ps*ps contiguous halfs = 1176 B at ps = 14) then leaves in 8-byte vector stores, one row after the other
+// (the direct form wrote 2-byte stores scattered over img/ps rows per pixel group).  The noise of pixel group `grp` depends
+// only on (seed, sample, grp), so the values are the ones the direct form produced.
 template <bool NOISE>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ src, int img, int ps,
                                                      int64_t first_sample, int na, int64_t first_b, int nb, float sigma,
                                                      uint64_t seed, half_t* __restrict__ A, int64_t lda, int per,
                                                      int64_t img_stride, int64_t row0) {
-    const int groups = 3 * img * img / 4;                       // 4 consecutive pixels of one image row
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)groups * nb) return;
-    const int b = (int)(gid / groups), grp = (int)(gid - (int64_t)b * groups);
-    const int e = grp * 4;
-    const int c = e / (img * img), rem = e - c * img * img;
-    const int y = rem / img, x0 = rem - y * img;
-    // NOISE: src is the single clean image x[3,img,img]; else src is the batch [nb,3,img,img]
+    extern __shared__ __attribute__((aligned(16))) half_t patch_lds[];   // [pw][kp]
+    const int pw = img / ps, kp = 3 * ps * ps;
+    const int b = blockIdx.x / pw, py = blockIdx.x - b * pw;
+    // NOISE: src is the clean image(s) x[.,3,img,img]; else src is the batch [nb,3,img,img]
     const int64_t rs = row0 + b;                                 // row in the sequence of all images
     const int im = (NOISE && per > 0) ? (int)(rs / per) : 0, j = (NOISE && per > 0) ? (int)(rs - (int64_t)im * per) : b;
-    float4 px = *reinterpret_cast<const float4*>(src + (NOISE ? (int64_t)im * 3 * img * img : (int64_t)b * 3 * img * img) + e);
-    if (NOISE) {
-        const int64_t sample = (j < na ? first_sample + j : first_b + (j - na)) + im * img_stride;
-        const float4 z = normal4(seed, (uint64_t)sample, (uint32_t)grp, 0u);
-        // explicit fma: the fused path and cgpt_noise_batch must round identically (bit-identical votes)
-        px.x = __fmaf_rn(sigma, z.x, px.x); px.y = __fmaf_rn(sigma, z.y, px.y);
-        px.z = __fmaf_rn(sigma, z.z, px.z); px.w = __fmaf_rn(sigma, z.w, px.w);
-        // keep the fp32 sum as its own value: otherwise hipcc fuses fma + f16 convert into v_fma_mixlo_f16 (ONE
-        // rounding), while the reference rounds batch + noise to fp32 first and autocast then casts to fp16.
-        asm volatile("" : "+v"(px.x), "+v"(px.y), "+v"(px.z), "+v"(px.w));
-    }
-    const int pw = img / ps;
-    const int py = y / ps, iy = y - py * ps;
-    const float vals[4] = {px.x, px.y, px.z, px.w};
+    const float* image = src + (NOISE ? (int64_t)im : (int64_t)b) * 3 * img * img;
+    const int64_t sample = NOISE ? (j < na ? first_sample + j : first_b + (j - na)) + im * img_stride : 0;
+    const int xg_per_row = img >> 2, groups = 3 * ps * xg_per_row;        // float4 groups of this patch row
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        const int c = g / (ps * xg_per_row), r = g - c * ps * xg_per_row;
+        const int iy = r / xg_per_row, x0 = (r - iy * xg_per_row) << 2;
+        const int e = (c * img + py * ps + iy) * img + x0;                // element index in the image; e/4 = noise group
+        float4 px = *reinterpret_cast<const float4*>(image + e);
+        if (NOISE) {
+            const float4 z = normal4(seed, (uint64_t)sample, (uint32_t)(e >> 2), 0u);
+            // explicit fma: the fused path and cgpt_noise_batch must round identically (bit-identical votes)
+            px.x = __fmaf_rn(sigma, z.x, px.x); px.y = __fmaf_rn(sigma, z.y, px.y);
+            px.z = __fmaf_rn(sigma, z.z, px.z); px.w = __fmaf_rn(sigma, z.w, px.w);
+            // keep the fp32 sum as its own value: otherwise hipcc fuses fma + f16 convert into v_fma_mixlo_f16 (ONE
+            // rounding), while the reference rounds batch + noise to fp32 first and autocast then casts to fp16.
+            asm volatile("" : "+v"(px.x), "+v"(px.y), "+v"(px.z), "+v"(px.w));
+        }
+        const float vals[4] = {px.x, px.y, px.z, px.w};
+        const int col0 = c * ps * ps + iy * ps;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = x0 + k;
-        const int pxi = x / ps, ix = x - pxi * ps;
-        const int64_t row = (int64_t)b * pw * pw + py * pw + pxi;
-        A[row * lda + c * ps * ps + iy * ps + ix] = (half_t)vals[k];
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + k;
+            const int pxi = x / ps, ix = x - pxi * ps;
+            patch_lds[pxi * kp + col0 + ix] = (half_t)vals[k];
+        }
+    }
+    __syncthreads();
+    half_t* out = A + ((int64_t)b * pw * pw + (int64_t)py * pw) * lda;   // first of this block's pw rows of A
+    if ((kp & 3) == 0 && (lda & 3) == 0) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const int q4 = kp >> 2;
+        for (int i = threadIdx.x; i < pw * q4; i += 256) {
+            const int pxi = i / q4, q = i - pxi * q4;
+            *reinterpret_cast<f16x4*>(out + (int64_t)pxi * lda + q * 4) = *reinterpret_cast<const f16x4*>(patch_lds + pxi * kp + q * 4);
+        }
+    } else {
+        for (int i = threadIdx.x; i < pw * kp; i += 256) {
+            const int pxi = i / kp, q = i - pxi * kp;
+            out[(int64_t)pxi * lda + q] = patch_lds[pxi * kp + q];
+        }
     }
 }
 
@@ -316,17 +338,24 @@ __global__ __launch_bounds__(256) void vote_kernel(const float* __restrict__ log
     const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= num) return;
     const float* row = logits + s * ld;
+    // torch.argmax / numpy argmax semantics (smoothing.py:97): a NaN ranks above every number, ties go to the lower index
+    auto beats = [](float v, int i, float bv, int bi) {
+        const bool vn = v != v, bn = bv != bv;
+        if (vn != bn) return vn;
+        if (vn) return i < bi;
+        return v > bv || (v == bv && i < bi);
+    };
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int k = lane; k < K; k += 64) {
         const float v = row[k];
-        if (v > best || bi == 0x7fffffff) { best = v; bi = k; }
+        if (bi == 0x7fffffff || beats(v, k, best, bi)) { best = v; bi = k; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o);
         const int oi = __shfl_xor(bi, o);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        if (beats(ov, oi, best, bi)) { best = ov; bi = oi; }
     }
     const int64_t rs = row0 + s;
     const int64_t im = per > 0 ? rs / per : 0, j = per > 0 ? rs - im * per : s;
@@ -422,10 +451,10 @@ inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + pe
 }  // namespace
 
 hipError_t launch_add_delta(float* x, int64_t ldx, const half_t* delta, int64_t ldd, int64_t rows, int D,
-                            hipStream_t stream) {
+                            hipStream_t stream, int skip_mod) {
     if (rows <= 0) return hipSuccess;
     if ((D & 1) || (ldx & 1) || (ldd & 1)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(add_delta_kernel, dim3(blocks_for(rows * (D >> 1))), dim3(256), 0, stream, x, ldx, delta, ldd, rows, D);
+    hipLaunchKernelGGL(add_delta_kernel, dim3(blocks_for(rows * (D >> 1))), dim3(256), 0, stream, x, ldx, delta, ldd, rows, D, skip_mod);
     return hipGetLastError();
 }
 
@@ -467,18 +496,18 @@ hipError_t launch_noise_im2col(const float* x, int img, int ps, int64_t first_sa
                                int64_t img_stride, int64_t row0) {
     if (nb <= 0) return hipSuccess;
     if ((img & 3) || (img % ps)) return hipErrorInvalidValue;
-    const int64_t n = (int64_t)nb * 3 * img * img / 4;
-    hipLaunchKernelGGL(im2col_kernel<true>, dim3(blocks_for(n)), dim3(256), 0, stream, x, img, ps, first_sample, na,
-                       first_b, nb, sigma, seed, A, lda, per, img_stride, row0);
+    const int pw = img / ps;
+    hipLaunchKernelGGL(im2col_kernel<true>, dim3((unsigned)(nb * pw)), dim3(256), (size_t)pw * 3 * ps * ps * sizeof(half_t), stream, x,
+                       img, ps, first_sample, na, first_b, nb, sigma, seed, A, lda, per, img_stride, row0);
     return hipGetLastError();
 }
 
 hipError_t launch_im2col(const float* images, int img, int ps, int nb, half_t* A, int64_t lda, hipStream_t stream) {
     if (nb <= 0) return hipSuccess;
     if ((img & 3) || (img % ps)) return hipErrorInvalidValue;
-    const int64_t n = (int64_t)nb * 3 * img * img / 4;
-    hipLaunchKernelGGL(im2col_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, stream, images, img, ps, (int64_t)0, nb,
-                       (int64_t)0, nb, 0.0f, (uint64_t)0, A, lda, 0, (int64_t)0, (int64_t)0);
+    const int pw = img / ps;
+    hipLaunchKernelGGL(im2col_kernel<false>, dim3((unsigned)(nb * pw)), dim3(256), (size_t)pw * 3 * ps * ps * sizeof(half_t), stream,
+                       images, img, ps, (int64_t)0, nb, (int64_t)0, nb, 0.0f, (uint64_t)0, A, lda, 0, (int64_t)0, (int64_t)0);
     return hipGetLastError();
 }
 

@@ -23,6 +23,32 @@ namespace cgpt {
 
 namespace {
 
+// Per-device launch state (a process may drive several GPUs: one handle per device): CU count and "dynamic LDS size
+// configured" flags are cached per device ordinal, not per process.
+constexpr int kMaxDevices = 64;
+struct DeviceInfo { int dev; int num_cus; };
+inline hipError_t device_info(DeviceInfo& out) {
+    static int cus[kMaxDevices] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    if (cus[dev] == 0) {
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        cus[dev] = n > 0 ? n : 256;
+    }
+    out.dev = dev; out.num_cus = cus[dev];
+    return hipSuccess;
+}
+template <typename KernelT>
+inline hipError_t configure_lds(KernelT kernel, int lds_bytes, bool (&done)[kMaxDevices], int dev) {
+    if (done[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
@@ -391,21 +417,12 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
 template <int EPI, int BN_>
 hipError_t launch_v2(const GemmParams& p, hipStream_t stream) {
     constexpr int lds_bytes = 2 * (256 + BN_) * BK * (int)sizeof(half_t);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_f16_kernel<EPI, BN_>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    DeviceInfo di;
+    if (hipError_t e = device_info(di); e != hipSuccess) return e;
+    static bool configured[kMaxDevices] = {false};
+    if (hipError_t e = configure_lds(&gemm2_f16_kernel<EPI, BN_>, lds_bytes, configured, di.dev); e != hipSuccess) return e;
     const int tiles = ((p.M + 255) / 256) * ((p.N + BN_ - 1) / BN_);
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int num_cus = di.num_cus;
     const int grid = tiles < num_cus ? tiles : num_cus;     // one 512-thread workgroup per CU (LDS-limited), persistent
     hipLaunchKernelGGL((gemm2_f16_kernel<EPI, BN_>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
@@ -734,21 +751,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
 template <int EPI, int NQ>
 hipError_t launch_v3(const GemmParams& p, hipStream_t stream) {
     constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_f16_kernel<EPI, NQ>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    DeviceInfo di;
+    if (hipError_t e = device_info(di); e != hipSuccess) return e;
+    static bool configured[kMaxDevices] = {false};
+    if (hipError_t e = configure_lds(&gemm3_f16_kernel<EPI, NQ>, lds_bytes, configured, di.dev); e != hipSuccess) return e;
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int num_cus = di.num_cus;
     const int grid = tiles < num_cus ? tiles : num_cus;
     hipLaunchKernelGGL((gemm3_f16_kernel<EPI, NQ>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
@@ -767,6 +775,7 @@ hipError_t launch_v3_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
 }
 
 
+#ifdef CGPT_LAB   // lab-only schedules (slower or equal; kept for A/B runs: make LAB=1)
 // ------------------------------------------------------------------------------------------------ v4
 // 256x256 tile, K-steps of 32 in an NS-deep ring of 32-KiB LDS stages (NS = 4: 128 KiB), LDS-DMA requests running
 // D = NS-1 sub-tiles ahead behind a COUNTED s_waitcnt vmcnt (never 0 in steady state), phase-alternating halves as v3.
@@ -915,21 +924,12 @@ __global__ __launch_bounds__(512, 2) void gemm4_f16_kernel(GemmParams p) {
 template <int EPI, int NS>
 hipError_t launch_v4(const GemmParams& p, hipStream_t stream) {
     constexpr int lds_bytes = NS * (256 + 256) * 32 * (int)sizeof(half_t);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_f16_kernel<EPI, NS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    DeviceInfo di;
+    if (hipError_t e = device_info(di); e != hipSuccess) return e;
+    static bool configured[kMaxDevices] = {false};
+    if (hipError_t e = configure_lds(&gemm4_f16_kernel<EPI, NS>, lds_bytes, configured, di.dev); e != hipSuccess) return e;
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int num_cus = di.num_cus;
     const int grid = tiles < num_cus ? tiles : num_cus;
     hipLaunchKernelGGL((gemm4_f16_kernel<EPI, NS>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
@@ -1108,21 +1108,12 @@ __global__ __launch_bounds__(512, 2) void gemm5_f16_kernel(GemmParams p) {
 template <int EPI>
 hipError_t launch_v5(const GemmParams& p, hipStream_t stream) {
     constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm5_f16_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    DeviceInfo di;
+    if (hipError_t e = device_info(di); e != hipSuccess) return e;
+    static bool configured[kMaxDevices] = {false};
+    if (hipError_t e = configure_lds(&gemm5_f16_kernel<EPI>, lds_bytes, configured, di.dev); e != hipSuccess) return e;
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int num_cus = di.num_cus;
     const int grid = tiles < num_cus ? tiles : num_cus;
     hipLaunchKernelGGL((gemm5_f16_kernel<EPI>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
@@ -1139,6 +1130,8 @@ hipError_t launch_v5_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
     }
 }
 
+#endif  // CGPT_LAB
+
 }  // namespace
 
 int g_gemm_kernel = 0;
@@ -1146,34 +1139,44 @@ int g_gemm_ablate = 0;
 int g_gemm_group_m = 4;   // measured: 4 ~ 8 > 2 > 16 (profiles/r01/gemm_variants.txt)
 unsigned long long* g_gemm_dbg = nullptr;
 
+// Result-preserving switches of gemm_ablate (each turns one optimisation off; outputs are bit-identical): the only bits a
+// production build honours.  Bits 1 / 2 / 4 (skip loads / stores / MFMAs: WRONG results, timing studies) exist in lab builds only.
+[[maybe_unused]] constexpr int kAblateSafeBits = 16 | 512 | 1024 | 8192 | 16384;
+
 hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
+#ifdef CGPT_LAB
     p.ablate = g_gemm_ablate;
     p.group_m = g_gemm_group_m;
     p.dbg = g_gemm_dbg;
+#else
+    p.ablate = g_gemm_ablate & kAblateSafeBits;
+    p.group_m = 4;
+    p.dbg = nullptr;
+#endif
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
         return hipErrorInvalidValue;
-    // Kernel choice (speed only).  v2 needs A readable for round_up(M,256) rows and W for round_up(N,256) rows: the
-    // library's activation and weight buffers are padded to 256 rows.
+    // Kernel choice (speed only; every kernel gives the same bits).  The 256-row kernels need A readable for round_up(M,256)
+    // rows and W for round_up(N,256) rows: the library's activation and weight buffers are padded to 256 rows.
     const bool vec_ok = (p.N % 4) == 0 && (p.ldo % 4) == 0 && (p.ldaux % 4) == 0;
-    const int force = vec_ok ? g_gemm_kernel : 1;   // 0 auto, 1 v1 (128x128), 2 v2 BN=256, 3 v2 BN=128  (cgpt_set_option)
-    if (force == 2) return launch_v2_epi<256>(epilogue, p, stream);   // W must be readable for round_up(N,256) rows
+    const int force = vec_ok ? g_gemm_kernel : 1;   // 0 auto, 1 = 128x128 register-staged, 3 = 256x128 direct-to-LDS, 4 = 256x256 phased
     if (force == 3 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
     if (force == 4) return launch_v3_epi<4>(epilogue, p, stream);
+#ifdef CGPT_LAB
+    if (force == 2) return launch_v2_epi<256>(epilogue, p, stream);
     if (force == 5) return launch_v3_epi<2>(epilogue, p, stream);
     if (force == 6) return launch_v4_epi<4>(epilogue, p, stream);
-    if (force == 8) return launch_v5_epi(epilogue, p, stream);
     if (force == 7) return launch_v4_epi<5>(epilogue, p, stream);
+    if (force == 8) return launch_v5_epi(epilogue, p, stream);
     if (force == 9) return launch_v6_epi(epilogue, 0, p, stream);
     if (force == 10) return launch_v6_epi(epilogue, 1, p, stream);
     if (force == 11) return launch_v8_epi(epilogue, p, stream);
+#endif
     if (force == 0 && p.M >= 1024) {
-        // measured on MI355X (profiles/r01/gemm_variants.txt): the 256x256 direct-to-LDS tile wins on every ViT / Q-Former
-        // shape, also when N is not a multiple of 256 (weights are allocated with 256-row padding); among the 256x256
-        // schedules the phase-alternating v3 with 4 phases per K-tile is the fastest inside the model (8.17 vs 7.95 img/s
-        // for v2; the 32-deep-K ring v4 is correct but slower).
-        // ... except when 256x256 tiles would leave more than half of the 256 CUs idle (the Q-Former's N = 768 linears at
-        // M = 200 x 32 rows: 75 tiles): there the 256x128 tile of v2 is 25-35 % faster (profiles/r01/gemm_variants.txt).
+        // measured on MI355X (profiles/r01/gemm_variants.txt): the 256x256 direct-to-LDS tile with the phase-alternating
+        // schedule wins on every ViT / Q-Former shape, also when N is not a multiple of 256 (weights are allocated with 256-row
+        // padding) ... except when 256x256 tiles would leave more than half of the 256 CUs idle (the Q-Former's N = 768 linears
+        // at M = 200 x 32 rows: 75 tiles): there the 256x128 tile is 25-35 % faster.
         const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         if (tiles256 <= 128 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
         return launch_v3_epi<4>(epilogue, p, stream);

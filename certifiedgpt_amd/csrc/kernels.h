@@ -31,12 +31,14 @@ struct GemmParams {
     int ablate = 0;               // measurement only: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
-hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);
-hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // gemm8.hip: two 4-wave workgroups per CU, 128x256 tiles   // gemm6.hip: 4-wave 128x128 wave tiles
+#ifdef CGPT_LAB
+hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);   // gemm6.hip: 4-wave 128x128 wave tiles
+hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // gemm8.hip: two 4-wave workgroups per CU, 128x256 tiles
+#endif
 extern int g_gemm_ablate;
 extern int g_gemm_group_m;
 extern unsigned long long* g_gemm_dbg;
-extern int g_gemm_kernel;   // kernel override for A/B measurements: 0 auto, 1 v1, 2 v2<256>, 3 v2<128>
+extern int g_gemm_kernel;   // kernel override (speed only): 0 auto, 1 = 128x128, 3 = 256x128, 4 = 256x256 phased; lab builds: 2, 5..11
 
 // ---------------------------------------------------------------------------------------- attention
 // O[b,q,h*hd + d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d]   (eva_vit.py:133-150,
@@ -60,9 +62,9 @@ hipError_t launch_layernorm(float* x, int64_t ldx, const half_t* delta, int64_t 
                             const float* beta, float eps, half_t* y16, int64_t ldy16, float* y32, int64_t ldy32,
                             int64_t rows, int D, hipStream_t stream, const half_t* delta2 = nullptr, int64_t ldd2 = 0,
                             int keep_x = 0);   // delta2: second pending update; keep_x: do not write x + updates back
-// x += delta without a LayerNorm (after the last block).
+// x += delta without a LayerNorm (after the last block).  skip_mod > 0: rows r with r % skip_mod == 0 are left alone.
 hipError_t launch_add_delta(float* x, int64_t ldx, const half_t* delta, int64_t ldd, int64_t rows, int D,
-                            hipStream_t stream);
+                            hipStream_t stream, int skip_mod = 0);
 
 // ------------------------------------------------------------------------------ noise / im2col / misc
 // smoothing.py:95-96 fused with the patch-embed im2col (eva_vit.py:202,209): for sample s = first_sample + b,

@@ -85,6 +85,7 @@ struct cgpt_model {
     half_t *Apatch, *xn, *qkv, *attn, *hid, *delta, *delta2, *cls16, *emb, *kv_all, *qh16, *qqkv, *qctx, *qq, *qff, *pooled;
     float *resid, *logits, *qemb0, *qh32, *qtmp, *llama;
     int last_nb = 0;
+    bool pending_delta = false;   // CGPT_MODE_VIT_HEAD: the last block's fc2 output has been added to the CLS rows only
     bool profile = false;
     std::vector<ProfEvent> events;
 };
@@ -322,6 +323,7 @@ cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_s
                     float sigma, uint64_t seed, hipStream_t st, int per = 0, int64_t img_stride = 0, int64_t row0 = 0) {
     const cgpt_config& c = m->cfg;
     const int D = m->D, Dk = m->Dk, T = m->T, P = m->P, M = nb * T;
+    m->pending_delta = false;
     // K1 + im2col: smoothing.py:95-96 fused into the patch-embed operand (eva_vit.py:202,209)
     if (noise) HIPCHK(launch_noise_im2col(src, c.img_size, c.patch_size, first_sample, na, first_b, nb, sigma, seed, m->Apatch, m->Kpatch_p, st, per, img_stride, row0));
     else HIPCHK(launch_im2col(src, c.img_size, c.patch_size, nb, m->Apatch, m->Kpatch_p, st));
@@ -349,9 +351,11 @@ cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_s
         CGCHK(gemm(m, EPI_F16, m->hid, m->mlp_k, L.Wfc2, m->mlp_k, L.bfc2, m->delta, Dk, nullptr, 0, M, D, m->mlp_k, 0, st));
     }
     if (c.mode == CGPT_MODE_VIT_HEAD) {
-        // last block's pending update, then ln_vision on the CLS rows only (row stride T*D) and the build-side head
-        HIPCHK(launch_add_delta(m->resid, D, m->delta, Dk, M, D, st));
-        HIPCHK(launch_layernorm(m->resid, (int64_t)T * D, nullptr, 0, m->lnvw, m->lnvb, c.ln_vision_eps, m->cls16, Dk, nullptr, 0, nb, D, st));
+        // ln_vision on the CLS rows only (row stride T*D), applying the last block's pending update to those rows on the way
+        // (the head reads nothing else; cgpt_get_activation("vit_out") applies it to the other rows on demand), then the head
+        HIPCHK(launch_layernorm(m->resid, (int64_t)T * D, m->delta, (int64_t)T * Dk, m->lnvw, m->lnvb, c.ln_vision_eps, m->cls16, Dk,
+                                nullptr, 0, nb, D, st));
+        m->pending_delta = true;
         CGCHK(gemm(m, EPI_F32, m->cls16, Dk, m->Whead, Dk, m->bhead, m->logits, m->K, nullptr, 0, nb, m->K, Dk, 0, st));
         m->last_nb = nb;
         return CGPT_OK;
@@ -616,6 +620,10 @@ cgpt_status cgpt_get_activation(cgpt_handle h, const char* what, float* out_dev,
     HIPCHK(hipSetDevice(h->cfg.device));
     if (w == "vit_out") {
         if (numel != (int64_t)nb * h->T * h->D) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_get_activation: numel mismatch");
+        if (h->pending_delta) {
+            HIPCHK(launch_add_delta(h->resid, h->D, h->delta, h->Dk, (int64_t)nb * h->T, h->D, st, h->T));
+            h->pending_delta = false;
+        }
         HIPCHK(hipMemcpyAsync(out_dev, h->resid, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else if (w == "ln_vision" && full) {
         if (numel != (int64_t)nb * h->T * h->D) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_get_activation: numel mismatch");
@@ -672,17 +680,33 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
     if (!key) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: null key");
     const std::string k(key);
     if (k == "gemm_kernel") {
-        if (value < 0 || value > 11) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_kernel must be 0..11");
+#ifdef CGPT_LAB
+        const bool ok = value >= 0 && value <= 11;
+#else
+        const bool ok = value == 0 || value == 1 || value == 3 || value == 4;
+#endif
+        if (!ok) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_kernel must be 0, 1, 3 or 4");
         g_gemm_kernel = value;
         return CGPT_OK;
     }
-    if (k == "gemm_ablate") { g_gemm_ablate = value; return CGPT_OK; }
-    if (k == "gemm_group_m") { if (value < 1) return cgpt_fail(CGPT_ERR_INVALID, "gemm_group_m >= 1"); g_gemm_group_m = value; return CGPT_OK; }   // measurement only (wrong results)
+    if (k == "gemm_ablate") {
+#ifndef CGPT_LAB
+        if (value & ~(16 | 512 | 1024 | 8192 | 16384))
+            return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_ablate accepts only the result-preserving bits 16|512|1024|8192|16384");
+#endif
+        g_gemm_ablate = value;
+        return CGPT_OK;
+    }
+#ifdef CGPT_LAB
+    if (k == "gemm_group_m") { if (value < 1) return cgpt_fail(CGPT_ERR_INVALID, "gemm_group_m >= 1"); g_gemm_group_m = value; return CGPT_OK; }
+#endif
     return cgpt_fail(CGPT_ERR_NOT_FOUND, "cgpt_set_option: unknown option '" + k + "'");
 }
 
-// diagnostic builds only: device buffer receiving per-wave cycle sums of the GEMM (not part of include/cgpt.h)
+#ifdef CGPT_LAB
+// lab builds only: device buffer receiving per-wave cycle sums of the GEMM (not part of include/cgpt.h)
 cgpt_status cgpt_debug_set_gemm_stamps(void* dev_buf) { g_gemm_dbg = (unsigned long long*)dev_buf; return CGPT_OK; }
+#endif
 
 cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on) {
     if (!h) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_profile_enable: null handle");

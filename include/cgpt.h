@@ -189,18 +189,15 @@ double cgpt_norm_ppf(double p);
 cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on);
 cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
 
-/* Process-wide tuning knobs for A/B measurements (never needed for correctness):
- *   "gemm_kernel": 0 = automatic choice; 1..11 force one GEMM kernel for A/B measurements (1 = 128x128 register-staged,
- *                  2/3 = 256x256 / 256x128 direct-to-LDS, 4/5 = phase-alternating 256x256 (4 = the automatic choice for
- *                  M >= 1024), 6/7 = K=32 ring, 8 = fragments one phase ahead, 9/10 = four-wave 128x128 wave tiles with
- *                  single / paired LDS-DMA requests, 11 = two 4-wave workgroups per CU on 128x256 tiles).  Results are identical
- *                  for every choice.
- *   "gemm_ablate": bit mask of measurement switches inside the GEMM kernels (0 in production).  Bits 16 / 512 / 1024 /
- *                  16384 turn off one optimisation each without changing results (early request of the next tile's first
- *                  K-tile, the LDS-transposed fp16 epilogue, the counted wait at tile start, the 192-column last tiles for
- *                  N = 256k+128), bit 8192 selects the register-exchange variant of the GELU epilogue (same results);
- *                  bits 1 and 2 skip the operand loads / the epilogue and give
- *                  WRONG results -- timing studies only (profiles/r01/gemm_variants.txt). */
+/* Process-wide SPEED knobs.  No option changes a result: every accepted value gives bit-identical outputs (tested).
+ *   "gemm_kernel": 0 = automatic choice (default); 1 = 128x128 register-staged tile, 3 = 256x128 direct-to-LDS tile,
+ *                  4 = 256x256 phase-alternating tile (the automatic choice for M >= 1024).
+ *   "gemm_ablate": bit mask; each bit turns ONE optimisation of the 256x256 kernel off without changing results:
+ *                  16 = early request of the next tile's first K-tile, 512 = LDS-transposed fp16 epilogue, 1024 = counted
+ *                  wait at tile start, 8192 = register-exchange instead of LDS-transposed GELU epilogue, 16384 = 192-column
+ *                  last tiles for N = 256k+128.  Any other bit is rejected with CGPT_ERR_INVALID.
+ * (A lab build of the library -- make LAB=1, never shipped -- additionally accepts the experimental schedules 2, 5..11 and
+ * timing-study switches that skip work; profiles/r01/gemm_variants.txt.) */
 cgpt_status cgpt_set_option(const char* key, int32_t value);
 
 /* ---- raw kernels exported for unit tests and reuse (all fp16 operands are IEEE binary16) ----
