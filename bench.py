@@ -15,6 +15,11 @@ with one all-reduce (same sample indices, counts, labels and radii as K separate
     (extra, NON-headline data points: --workload encode_img | rgf, --img-size 448, --n 1000 / --n0 K)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment is a self-contained N-rank run: this process -- before it touches
+the GPU -- starts `python -m torch.distributed.run --nproc-per-node N` on this file as a CHILD process (one rank per GPU, as the
+reference's launcher starts one process per device, launch.py:110-120), relays its output and exits with its code.  A rank whose
+WORLD_SIZE differs from --gpus, or a node with fewer than N devices, is an error (exit code 2), never a silent 1-GPU measurement.
+
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the MLP fc1 GEMM with the GELU epilogue,
 gemm3_f16_kernel<EPI_F16_GELU, 4>): achieved = 2*M*6144*1408 FLOP per launch / its mean launch duration measured with HIP
 events on the launch stream inside the timed region.  `cpu_baseline` times the CPU oracle (oracle/, a port of the
@@ -46,37 +51,86 @@ def synthetic_images(count, device, img=224):
     return ((u - mean) / std).to(device)
 
 
-def cpu_baseline(clf, x, seconds_budget=25.0):
-    """The oracle's Smooth hot loop on the host cores, same weights / image / noise stream as the GPU run, bounded sample."""
-    import numpy as np
-    import certifiedgpt_amd as cg
-    from oracle import model_oracle as mo
-    cfg = mo.Config(mode=mo.MODE_VIT_HEAD, num_classes=NUM_CLASSES)
-    params = {n: torch.from_numpy(clf.get_weight(n)).reshape(s) for n, s in mo.param_shapes(cfg).items()}
-    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+def host_cores():
+    """The GPU box gives one GPU's share of the host; os.cpu_count() reports the whole machine."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("CGPT_CPU_THREADS", "16"))))
+    return max(1, min(cores, int(os.environ.get("CGPT_CPU_THREADS", "64"))))
+
+
+def cpu_baseline_and_parity(clf, x):
+    """BASELINE configs[0] on both sides, in this run: ONE whole `Smooth.certify(x, n0=10, n=10, alpha=0.001, batch_size=10)`
+    at sigma = 0.25 (a) timed on the host cores with the CPU oracle (oracle/smooth_oracle.py around the fp32 PyTorch-CPU
+    ViT-G of oracle/model_oracle.py: the restatement of the reference's smoothing.py:29-56 + eva_vit.py, same weights --
+    downloaded from the device -- same image, and the GPU's own noise draws, exported), and (b) run on the GPU through the
+    product path.  Returns (cpu_baseline, parity): the timed CPU figure scaled to the headline unit, and the comparison of the
+    two results (label, abstain, radius, per-sample argmax agreement)."""
+    import numpy as np
+    import certifiedgpt_amd as cg
+    from oracle import model_oracle as mo, smooth_oracle as so
+    n0 = n = 10
+    sigma, alpha, seed = 0.25, 0.001, 42
+    cfg = mo.Config(mode=mo.MODE_VIT_HEAD, num_classes=NUM_CLASSES)
+    params = {name: torch.from_numpy(clf.get_weight(name)).reshape(shape) for name, shape in mo.param_shapes(cfg).items()}
+    cores = host_cores()
     torch.set_num_threads(cores)
-    bs, done, t_used = 4, 0, 0.0
-    counts = np.zeros(NUM_CLASSES, dtype=int)
-    while True:
-        noisy = cg.noise_batch(x, done, bs, SIGMA, 42).cpu()          # identical draws to the GPU stream
-        t0 = time.perf_counter()
-        logits = mo.forward_all(params, noisy, cfg)["logits"]
-        counts += np.bincount(logits.argmax(1).numpy(), minlength=NUM_CLASSES)
-        t_used += time.perf_counter() - t0
-        done += bs
-        if t_used >= seconds_budget * 0.6 or done >= 40:
-            break
-    fwd_per_s = done / t_used
-    return {"value": fwd_per_s / (N0 + N), "unit": "certified images/s", "cores": cores, "threads": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{done} of the {N0 + N} noisy ViT-G forwards of one certify (batch {bs}, fp32 PyTorch-CPU oracle), "
-                      f"{t_used:.1f} s; rate extrapolated to n0+n={N0 + N} forwards per image",
-            "forwards_per_s": fwd_per_s}
+    # GPU side first (also exports the N(0,1) draws the CPU side must see)
+    smooth = cg.Smooth(clf, NUM_CLASSES, sigma, seed=seed)
+    gpu_label, gpu_radius = smooth.certify(x, n0, n, alpha, 10)
+    gpu_logits = clf.forward_logits(x, 0, n0 + n, sigma, seed).cpu()
+    draws = cg.noise_batch(torch.zeros_like(x), 0, n0 + n, 1.0, seed).cpu().numpy()
+
+    cpu_logits = []
+
+    def classifier(batch):
+        out = mo.forward_all(params, torch.from_numpy(np.ascontiguousarray(batch)), cfg)["logits"]
+        cpu_logits.append(out)
+        return out.numpy()
+
+    oracle = so.SmoothOracle(classifier, NUM_CLASSES, sigma, lambda first, num, shape: draws[first:first + num])
+    t0 = time.perf_counter()
+    cpu_label, cpu_radius = oracle.certify(x.cpu().numpy(), n0, n, alpha, 10)
+    cpu_s = time.perf_counter() - t0
+    cpu_logits = torch.cat(cpu_logits)
+    agree = int((cpu_logits.argmax(1) == gpu_logits.argmax(1)).sum())
+    top2 = cpu_logits.topk(2, dim=1).values
+    margin = ((top2[:, 0] - top2[:, 1]) / cpu_logits.abs().max()).tolist()
+    fwd_per_s = (n0 + n) / cpu_s
+    baseline = {"value": fwd_per_s / (N0 + N), "unit": "certified images/s", "cores": cores, "threads": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"one whole Smooth.certify of BASELINE configs[0] (n0={n0}, n={n}, sigma={sigma}, alpha={alpha}: {n0 + n} ViT-G "
+                          f"forwards in batches of 10, fp32 PyTorch-CPU oracle) timed at {cpu_s:.1f} s; value = its forwards/s scaled "
+                          f"to the headline's n0+n={N0 + N} forwards per certified image",
+                "config0_certify_s": cpu_s, "config0_images_per_s": 1.0 / cpu_s, "forwards_per_s": fwd_per_s}
+    parity = {"config": f"BASELINE configs[0]: Smooth.certify n0={n0} n={n} sigma={sigma} alpha={alpha}, ViT-G + head, same weights / image / noise draws",
+              "gpu": [int(gpu_label), float(gpu_radius)], "cpu_oracle": [int(cpu_label), float(cpu_radius)],
+              "label_equal": int(gpu_label) == int(cpu_label), "abs_dR": abs(float(gpu_radius) - float(cpu_radius)),
+              "argmax_agreement": f"{agree}/{n0 + n}", "min_fp32_top2_margin_rel": min(margin),
+              "logits_rel_err": float((gpu_logits - cpu_logits).abs().max() / cpu_logits.abs().max())}
+    return baseline, parity
+
+
+def launch_ranks(n, argv):
+    """Parent of a self-contained N-rank run: start the ranks as a child process and relay its exit code.  Nothing in this
+    process has touched the GPU (torch.cuda.device_count() does not initialise it)."""
+    import socket
+    import subprocess
+    rehearsal = bool(os.environ.get("CGPT_BENCH_ONE_GPU_REHEARSAL"))
+    have = torch.cuda.device_count()
+    if have < n and not rehearsal:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible on this node; refusing to measure a smaller configuration",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -96,21 +150,33 @@ def main():
     rgf = args.workload == "rgf"                     # BASELINE configs[4]: 8-step RGF x smoothed predict(N) on ViT-G + head
     mode = "vit_head" if rgf else args.workload
 
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # self-contained N-rank run: the ranks are a child process
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("CGPT_BENCH_ONE_GPU_REHEARSAL"):      # rehearse the N > 1 code path on a one-GPU box: all ranks on cuda:0, gloo
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}: refusing to measure a different configuration", file=sys.stderr)
+        sys.exit(2)
+    rehearsal = bool(os.environ.get("CGPT_BENCH_ONE_GPU_REHEARSAL"))   # the N > 1 code path on a one-GPU box: all ranks on cuda:0, gloo
+    if rehearsal:
         local = 0
+    elif torch.cuda.device_count() <= local:
+        print(f"bench.py: rank {rank} wants cuda:{local} but {torch.cuda.device_count()} device(s) are visible", file=sys.stderr)
+        sys.exit(2)
     import torch.distributed as dist
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        backend = "gloo" if os.environ.get("CGPT_BENCH_ONE_GPU_REHEARSAL") else "nccl"   # "nccl" IS RCCL on ROCm
+        backend = "gloo" if rehearsal else "nccl"            # "nccl" IS RCCL on ROCm
         dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == backend
     else:
         torch.cuda.set_device(local)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     import certifiedgpt_amd as cg
     if os.environ.get("CGPT_GEMM_KERNEL"):          # A/B measurements only; default = the library's own choice
@@ -199,13 +265,30 @@ def main():
     fc1_ms, fc1_flops, fc1_n = clf.profile_read(1)
     all_ms, all_flops, all_n = clf.profile_read(0)
 
+    # The reference-shaped call, outside the timed region: ONE Smooth.certify(x, n0, n, alpha, batch_size = n0 + n) per image
+    # (smoothing.py:29-56), i.e. no grouping of images; every rank takes part (its shard + the all-reduce).
+    single_ms = None
+    if not rgf:
+        reps = 3
+        smooth.certify(images[0], n_sel, n_est, ALPHA, n_sel + n_est)
+        torch.cuda.synchronize()
+        barrier()
+        ts = time.perf_counter()
+        for i in range(reps):
+            smooth.certify(images[i % len(images)], n_sel, n_est, ALPHA, n_sel + n_est)
+        torch.cuda.synchronize()
+        barrier()
+        single_ms = 1e3 * (time.perf_counter() - ts) / reps
+
     if rank == 0:
         value = args.steps / elapsed
         fc1_tflops = fc1_flops / (fc1_ms * 1e-3) / 1e12 if fc1_ms > 0 else 0.0
         all_tflops = all_flops / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
         line = {
             "metric": "certified images/sec (N=100, sigma=0.5)", "value": value, "unit": "certified images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "rccl_ranks": world if backend == "nccl" else (0 if world > 1 else 1),
+            "collective_backend": backend or "none (single rank)",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": "EVA-ViT-G encoder + ln_vision(CLS) + Linear head, random-init weights, 224x224 synthetic "
@@ -226,6 +309,9 @@ def main():
                          "all_gemms": {"achieved": all_tflops, "frac": all_tflops / MFMA_PEAK_TFLOPS, "launches": all_n,
                                        "total_ms": all_ms}},
             "results_sample": [[int(l), float(r)] for l, r in results[-3:]],
+            "single_image_certify_ms": single_ms,
+            "single_image_certify_note": "one reference-shaped Smooth.certify(x, n0, n, alpha, batch_size=n0+n) per image, no grouping "
+                                         "of images (the headline value sends groups of images through Smooth.certify_many)",
         }
         if not headline:
             T = (args.img_size // 14) ** 2 + 1
@@ -244,7 +330,7 @@ def main():
             line["roofline"]["flop_per_launch"] = fc1_flops / max(fc1_n, 1)
         if world == 1 and not args.no_cpu_baseline and headline:
             try:
-                line["cpu_baseline"] = cpu_baseline(clf, images[0])
+                line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(clf, images[0])
                 line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
             except Exception as e:  # the CPU leg must never void the GPU measurement
                 line["cpu_baseline"] = {"error": repr(e)}

@@ -49,6 +49,8 @@ SIGNATURES = {
     "cgpt_sample_counts_images": (_I32, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _F, _U64, _P]),
     "cgpt_forward_logits": (_I32, [_P, _P, _I64, _I64, _F, _U64, _P, _P]),
     "cgpt_classify": (_I32, [_P, _P, _I64, _P, _P]),
+    "cgpt_encode_img": (_I32, [_P, _P, _I64, _P, _P]),
+    "cgpt_encode_img_noisy": (_I32, [_P, _P, _I64, _I64, _F, _U64, _P, _P]),
     "cgpt_get_activation": (_I32, [_P, C.c_char_p, _P, _I64, _P]),
     "cgpt_noise_batch": (_I32, [_P, _I64, _I64, _I64, _F, _U64, _P, _P]),
     "cgpt_rgf_step": (_I32, [_P, _P, _I64, _I64, _I32, _P, _F, _F, _U64, _P, _P]),

@@ -1,12 +1,13 @@
 """Text -> label adapter ("decoder-to-label" mapping, reference README.md:28-29; there is NO code for it in the reference).
 
-A generated answer string is normalised and looked up in a growing answer vocabulary capped at `num_classes`; answers that
-arrive after the vocabulary is full map to the last class ("other").  The normaliser is build-side and deliberately small:
-lower-case, tabs/newlines -> space, punctuation removed (or turned into a space between alphanumerics), periods that are not
-decimal points dropped, English articles dropped, number words zero..ten -> digits.  It follows the *order* of operations of
-the VQA accuracy normaliser the reference ships for scoring (common/vqa_tools/vqa_eval.py:211-216 answer clean-up, :249-259
-punctuation, :261-274 digits/articles) but does NOT carry its contraction table; tests/golden/label_adapter_golden.json holds
-outputs of the reference's own normaliser on answers without contractions, which this one must reproduce.
+A generated answer string is normalised and looked up in an answer vocabulary of at most `num_classes - 1` entries; the last
+class id is "other".  The normaliser reproduces the VQA accuracy normaliser the reference ships for scoring
+(common/vqa_tools/vqa_eval.py:211-216 answer clean-up, :249-259 punctuation, :261-274 number words / articles / contractions),
+including its quirks (the `(?!<=\d)` look-ahead typo, the reversed "somebody'd" entry, and the fact that its capitalised
+contraction keys can never match a lower-cased word).  tests/golden/label_adapter_golden.json holds outputs of the reference's
+own normaliser -- every key of its contraction table among them -- which this one must reproduce.
+
+The contraction table is generated from its grammar (stem x suffix) instead of being listed entry by entry.
 """
 import re
 
@@ -16,6 +17,36 @@ _NUMBERS = {"none": "0", "zero": "0", "one": "1", "two": "2", "three": "3", "fou
 _PUNCT = ";/[]\"{}()=+\\_-><@`,?!"
 _PERIOD = re.compile(r"(?!<=\d)(\.)(?!\d)")
 _COMMA_NUM = re.compile(r"(\d)(,)(\d)")
+
+
+def _build_contractions():
+    """apostrophe-less (or half-apostrophised) word -> contraction, as vqa_eval.py:29-150 defines it."""
+    t = {}
+    for stem in ("ai", "are", "ca", "could", "did", "does", "do", "had", "has", "have", "is", "might", "must", "need", "ought",
+                 "sha", "should", "was", "were", "wo", "would"):
+        t[stem + "nt"] = stem + "n't"
+    for stem in ("could", "had", "might", "should", "would"):
+        t[stem + "nt've"] = t[stem + "n'tve"] = stem + "n't've"
+    for stem in ("could", "might", "must", "should", "would", "not", "they", "we", "who", "you", "what", "where"):
+        t[stem + "ve"] = stem + "'ve"
+    for stem in ("he", "how", "it", "they", "where", "who", "you", "someone", "something", "there"):
+        t[stem + "d"] = stem + "'d"
+    for stem in ("he", "it", "she", "somebody", "someone", "something", "there", "they", "we", "who", "you"):
+        t[stem + "d've"] = t[stem + "'dve"] = stem + "'d've"
+    for stem in ("how", "it", "somebody", "someone", "something", "they", "what", "who", "why", "you"):
+        t[stem + "ll"] = stem + "'ll"
+    for stem in ("he", "how", "somebody", "someone", "that", "there", "what", "when", "where", "who", "why"):
+        t[stem + "s"] = stem + "'s"
+    for stem in ("there", "they", "what", "why", "you"):
+        t[stem + "re"] = stem + "'re"
+    t.update({"maam": "ma'am", "oclock": "o'clock", "twas": "'twas", "yall": "y'all", "let's": "let's", "she's": "she's",
+              "yall'll": "y'all'll", "y'allll": "y'all'll", "yall'd've": "y'all'd've", "y'alld've": "y'all'd've",
+              "y'all'dve": "y'all'd've", "ow's'at": "'ow's'at", "'ows'at": "'ow's'at", "'ow'sat": "'ow's'at",
+              "somebody'd": "somebodyd"})        # the last one is the reference's own (reversed) entry
+    return t
+
+
+_CONTRACTIONS = _build_contractions()
 
 
 def normalize_answer(text: str) -> str:
@@ -28,32 +59,62 @@ def normalize_answer(text: str) -> str:
             out = out.replace(p, " ")
     out = _PERIOD.sub("", out)
     words = [_NUMBERS.get(w, w) for w in out.lower().split()]
-    return " ".join(w for w in words if w not in _ARTICLES)
+    return " ".join(_CONTRACTIONS.get(w, w) for w in words if w not in _ARTICLES)
 
 
 class AnswerLabelMap:
-    """Growing {normalised answer: class id}; class ids are dense in order of first appearance; id num_classes-1 is 'other'
-    once the vocabulary is full.  The same map must be used for every noisy sample of an image (and across images of a run),
-    so that votes are comparable."""
+    """{normalised answer: class id}.  Class ids 0 .. num_classes-2 are answers in vocabulary order; id num_classes-1 is
+    "other" (`other_id`): every answer outside the vocabulary.  "other" is not a class of the base classifier in the sense of
+    the certificate (it lumps unrelated answers together), so callers treat a top class of `other_id` as ABSTAIN
+    (`Smooth(..., non_certifiable=(label_map.other_id,))`).
 
-    def __init__(self, num_classes: int, vocabulary=()):
+    The base classifier must be a FIXED function of the image for the certificate to hold, so the vocabulary should be given
+    up front and the map frozen.  An unfrozen map grows in order of first appearance (single process, exploratory use only):
+    under torch.distributed with more than one rank that would give the same answer different ids on different ranks (each
+    rank sees different noisy samples) and the all-reduce would sum unrelated classes -- growing there raises."""
+
+    def __init__(self, num_classes: int, vocabulary=(), frozen=None):
         assert num_classes >= 2
         self.num_classes = num_classes
         self.to_id = {}
         self.answers = []
-        for a in vocabulary:
-            self(a)
+        self.frozen = False
+        for a in vocabulary:                                   # given up front: the same on every rank by construction
+            key = normalize_answer(a)
+            if key not in self.to_id and len(self.answers) < self.num_classes - 1:
+                self.to_id[key] = len(self.answers)
+                self.answers.append(key)
+        # a vocabulary given up front freezes the map unless the caller says otherwise
+        self.frozen = bool(vocabulary) if frozen is None else bool(frozen)
+
+    @property
+    def other_id(self) -> int:
+        return self.num_classes - 1
+
+    def freeze(self):
+        self.frozen = True
+        return self
+
+    @staticmethod
+    def _multi_rank() -> bool:
+        try:
+            import torch.distributed as dist
+            return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        except Exception:
+            return False
 
     def __call__(self, text: str) -> int:
         key = normalize_answer(text)
         idx = self.to_id.get(key)
         if idx is None:
-            if len(self.answers) < self.num_classes - 1:
-                idx = len(self.answers)
-                self.to_id[key] = idx
-                self.answers.append(key)
-            else:
-                idx = self.num_classes - 1
+            if self.frozen or len(self.answers) >= self.num_classes - 1:
+                return self.other_id
+            if self._multi_rank():
+                raise RuntimeError("AnswerLabelMap would grow under torch.distributed (ids would differ between ranks): "
+                                   "pass the answer vocabulary up front (it is then frozen)")
+            idx = len(self.answers)
+            self.to_id[key] = idx
+            self.answers.append(key)
         return idx
 
     def one_hot_logits(self, texts, device=None):

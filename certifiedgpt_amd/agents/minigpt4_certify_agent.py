@@ -8,7 +8,10 @@ Config (a plain dict or any mapping; the reference's YAMLs define no smoothing k
     run:   {agent: image_text_certify, output_dir: ..., seed: 0,
             smoothing: {sigma: 0.5, n0: 100, n: 100, alpha: 0.001, batch_size: 100, num_classes: 1000, radii: [0.25, 0.5, 1.0],
                         images_per_pass: 1}}      # > 1: Smooth.certify_many (multi-GPU throughput mode)
-    model: {mode: vit_head | encode_img, weights: <path to a torch state_dict saved with torch.save> | null, dims: {...}}
+    model: {generate: {llama_model: <LOCAL dir>, prompt | question: ..., answers: [...], max_new_tokens: 20},   # optional: full
+            #          MiniGPT-4 `generate` as the base classifier (certifiedgpt_amd/minigpt4.py); classes = the answer vocabulary
+            mode: vit_head | encode_img, weights: <path to a torch state_dict saved with torch.save> | null, dims: {...},
+            partial_weights: false}   # true: load what the checkpoint has on top of the synthetic initialisation
     data:  {num_images: 10, seed: 1234}      # synthetic CLIP-normalised images unless `dataset` is passed to the agent
 """
 import json
@@ -95,16 +98,75 @@ class CertifyLoop:
         return out
 
 
-def build_classifier(model_cfg, num_classes, max_batch, device_index):
+def prepare_state_dict(state, expected_names, allow_partial=False):
+    """Checkpoint -> {library weight name: tensor}, accepting the layouts the reference saves / loads:
+      * a wrapper dict with the weights under "model" (BLIP-2 / Q-Former / MiniGPT-4 checkpoints, base_model.py:59,261) or
+        "model_state_dict" (this build's agents), or a bare state_dict;
+      * raw EVA-ViT checkpoints, whose keys have no "visual_encoder." prefix (eva_vit.py:445-456 loads them into the
+        encoder module itself).
+    Keys the library does not know (the text branch of the Q-Former, the LLM, LoRA weights) are dropped.  Every weight of
+    the library is zero until loaded, so a name mismatch would silently leave a layer at zero -- and a ViT whose LayerNorm
+    gains are zero votes the head bias on every noisy sample, i.e. certifies the maximum radius for a model that never
+    loaded.  Unless allow_partial is set (then the caller must have initialised the weights first), any library weight the
+    checkpoint does not cover is an error."""
+    for key in ("model", "model_state_dict", "state_dict"):
+        if isinstance(state, dict) and key in state and isinstance(state[key], dict):
+            state = state[key]
+            break
+    expected = set(expected_names)
+    out = {}
+    for k, v in state.items():
+        if k in expected:
+            out[k] = v
+        elif "visual_encoder." + k in expected:
+            out["visual_encoder." + k] = v
+    missing = sorted(expected - set(out))
+    if missing and not allow_partial:
+        raise KeyError(f"checkpoint covers {len(out)} of {len(expected)} weights; missing e.g. {missing[:4]} "
+                       f"(set model.partial_weights: true to load on top of the synthetic initialisation)")
+    return out, missing
+
+
+def build_generating_classifier(encoder, gen_cfg, num_classes, tokenizer=None, llama_model=None):
+    """Full MiniGPT-4 as the base classifier (BASELINE configs[2]): `encoder` (HipClassifier, mode encode_img) + a frozen
+    causal LM on PyTorch-ROCm, loaded BY LOCAL PATH only (base_model.py:181-247 loads `llama_model` the same way; nothing is
+    ever fetched), + the answer vocabulary that defines the classes.
+        gen_cfg: {llama_model: <local dir>, prompt: "... <ImageHere> ...", answers: [...], max_new_tokens: 20}"""
+    from ..minigpt4 import MiniGPT4Classifier, prepare_texts
+    from .label_adapter import AnswerLabelMap
+    if llama_model is None:
+        from transformers import AutoModelForCausalLM
+        llama_model = AutoModelForCausalLM.from_pretrained(gen_cfg["llama_model"], torch_dtype=torch.float16,
+                                                           local_files_only=True).to(encoder.device).eval()
+    if tokenizer is None:
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(gen_cfg.get("llama_tokenizer", gen_cfg["llama_model"]), local_files_only=True,
+                                                  use_fast=False)
+    for p_ in llama_model.parameters():                      # frozen decoder, base_model.py:236-238
+        p_.requires_grad = False
+    prompt = gen_cfg.get("prompt") or prepare_texts(["<Img><ImageHere></Img> " + gen_cfg.get("question", "")])[0]
+    label_map = AnswerLabelMap(num_classes, gen_cfg.get("answers", ()), frozen=True)
+    return MiniGPT4Classifier(encoder, llama_model, tokenizer, prompt, label_map,
+                              max_new_tokens=int(gen_cfg.get("max_new_tokens", 20)), max_batch=encoder.max_batch)
+
+
+def build_classifier(model_cfg, num_classes, max_batch, device_index, tokenizer=None, llama_model=None):
     from ..classifier import HipClassifier
-    clf = HipClassifier(mode=model_cfg.get("mode", "vit_head"), num_classes=num_classes, max_batch=max_batch,
-                        device=device_index, **model_cfg.get("dims", {}))
+    generating = "generate" in model_cfg
+    clf = HipClassifier(mode="encode_img" if generating else model_cfg.get("mode", "vit_head"), num_classes=num_classes,
+                        max_batch=max_batch, device=device_index, **model_cfg.get("dims", {}))
     path = model_cfg.get("weights")
     if path:
+        partial = bool(model_cfg.get("partial_weights", False))
+        if partial:                                   # e.g. a pretrained encoder + the build-side head left synthetic
+            clf.init_synthetic(seed=int(model_cfg.get("seed", 0)))
         state = torch.load(path, map_location="cpu", weights_only=True)
-        clf.load_state_dict(state.get("model_state_dict", state), strict=False)
+        state, _ = prepare_state_dict(state, clf.weight_names(), allow_partial=partial)
+        clf.load_state_dict(state, strict=False)
     else:
         clf.init_synthetic(seed=int(model_cfg.get("seed", 0)))
+    if generating:
+        return build_generating_classifier(clf, model_cfg["generate"], num_classes, tokenizer, llama_model)
     return clf
 
 
@@ -112,24 +174,30 @@ def build_classifier(model_cfg, num_classes, max_batch, device_index):
 class MiniGPT4CertifyAgent(BaseAgent, CertifyLoop):
     mode = "certify"
 
-    def __init__(self, dataset=None, classifier=None):
+    def __init__(self, dataset=None, classifier=None, tokenizer=None, llama_model=None):
         super().__init__()
         self.dataset = dataset
         self.classifier = classifier
+        self.tokenizer = tokenizer              # optional overrides of what model.generate.{llama_tokenizer,llama_model} would load
+        self.llama_model = llama_model
         self.result = None
 
     def run(self):
         cfg = self.config
         sm = dict(cfg["run"]["smoothing"])
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        clf = self.classifier or build_classifier(cfg.get("model", {}), sm["num_classes"], sm["batch_size"], local)
+        clf = self.classifier or build_classifier(cfg.get("model", {}), sm["num_classes"], sm["batch_size"], local,
+                                                  self.tokenizer, self.llama_model)
         self._model = clf
         self._device = getattr(clf, "device", None)
-        smooth = Smooth(clf, sm["num_classes"], sm["sigma"], seed=int(cfg["run"].get("seed", 0)))
+        # a generating classifier's "other" bucket (answers outside the vocabulary) is not a class of the certificate
+        label_map = getattr(clf, "label_map", None)
+        smooth = Smooth(clf, sm["num_classes"], sm["sigma"], seed=int(cfg["run"].get("seed", 0)),
+                        non_certifiable=(label_map.other_id,) if label_map is not None else ())
         data = self.dataset
         if data is None:
             d = cfg.get("data", {})
-            img = getattr(clf, "chw", (3, 224, 224))[1]
+            img = getattr(getattr(clf, "encoder", clf), "chw", (3, 224, 224))[1]
             data = synthetic_dataset(int(d.get("num_images", 10)), img, int(d.get("seed", 1234)), self._device, sm["num_classes"])
         out_dir = cfg["run"].get("output_dir")
         log = None

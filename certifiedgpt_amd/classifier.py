@@ -160,6 +160,25 @@ class HipClassifier:
                                                      image_stride, C.c_void_p(counts.data_ptr()), sigma, seed, _stream_ptr()))
         return counts
 
+    def encode_img(self, images):
+        """MiniGPT4.encode_img (minigpt4.py:121-149): [B,3,H,W] float32 -> (inputs_llama [B, queries, proj_dim] float32,
+        atts_llama ones [B, queries] long).  mode="encode_img" classifiers only."""
+        images = self._check_x(images, True)
+        B = images.shape[0]
+        out = torch.empty((B, self.cfg["qf_queries"], self.cfg["proj_dim"]), dtype=torch.float32, device=images.device)
+        _lib.check(self._L.cgpt_encode_img(self._h, C.c_void_p(images.data_ptr()), B, C.c_void_p(out.data_ptr()), _stream_ptr()))
+        return out, torch.ones(out.shape[:-1], dtype=torch.long, device=images.device)
+
+    def encode_img_noisy(self, x, first_sample, num, sigma, seed):
+        """encode_img(x + sigma * eps_s) for the samples s = first_sample .. first_sample+num-1 of the noise stream, the noise
+        fused into the patch-embed operand (cgpt_encode_img_noisy) -> inputs_llama [num, queries, proj_dim] float32."""
+        x = self._check_x(x, False)
+        out = torch.empty((num, self.cfg["qf_queries"], self.cfg["proj_dim"]), dtype=torch.float32, device=x.device)
+        if num > 0:
+            _lib.check(self._L.cgpt_encode_img_noisy(self._h, C.c_void_p(x.data_ptr()), first_sample, num, sigma, seed,
+                                                     C.c_void_p(out.data_ptr()), _stream_ptr()))
+        return out
+
     def forward_logits(self, x, first_sample, num, sigma, seed):
         x = self._check_x(x, False)
         out = torch.empty((num, self.num_classes), dtype=torch.float32, device=x.device)

@@ -319,8 +319,11 @@ cgpt_status attention(const half_t* Q, int64_t ldq, int64_t qbs, const half_t* K
 
 // One base-classifier forward for nb samples.  src: the clean image (noise=true) or nb images (noise=false).
 // With noise: batch row b is sample first_sample + b for b < na, first_b + (b - na) otherwise.
+// llama_out != nullptr (CGPT_MODE_ENCODE_IMG only): llama_proj writes its [nb*Q, proj_dim] fp32 output straight into that
+// caller buffer and the build-side head is skipped (cgpt_encode_img*: the consumer is an LLM, not the vote).
 cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_sample, int na, int64_t first_b, int nb,
-                    float sigma, uint64_t seed, hipStream_t st, int per = 0, int64_t img_stride = 0, int64_t row0 = 0) {
+                    float sigma, uint64_t seed, hipStream_t st, int per = 0, int64_t img_stride = 0, int64_t row0 = 0,
+                    float* llama_out = nullptr) {
     const cgpt_config& c = m->cfg;
     const int D = m->D, Dk = m->Dk, T = m->T, P = m->P, M = nb * T;
     m->pending_delta = false;
@@ -387,6 +390,11 @@ cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_s
         CGCHK(gemm(m, EPI_F16_GELU, m->qh16, Hk, L.Wi, Hk, L.bi, m->qff, m->Fk, nullptr, 0, MQ, m->F, Hk, 0, st));
         CGCHK(gemm(m, EPI_RESID, m->qff, m->Fk, L.Wo2, m->Fk, L.bo2, m->qtmp, H, m->qh32, H, MQ, H, m->Fk, 0, st));
         HIPCHK(launch_layernorm(m->qtmp, H, nullptr, 0, L.ln2w, L.ln2b, c.qf_ln_eps, m->qh16, Hk, m->qh32, H, MQ, H, st));
+    }
+    if (llama_out) {                                                          // inputs_llama, minigpt4.py:141
+        CGCHK(gemm(m, EPI_F32, m->qh16, Hk, m->Wproj_l, Hk, m->bproj_l, llama_out, m->PD, nullptr, 0, MQ, m->PD, Hk, 0, st));
+        m->last_nb = 0;                                                       // the workspace no longer holds a complete forward
+        return CGPT_OK;
     }
     CGCHK(gemm(m, EPI_F32, m->qh16, Hk, m->Wproj_l, Hk, m->bproj_l, m->llama, m->PD, nullptr, 0, MQ, m->PD, Hk, 0, st));
     // build-side label head on the mean of the query tokens
@@ -607,6 +615,38 @@ cgpt_status cgpt_classify(cgpt_handle h, const float* images_dev, int64_t num, f
     HIPCHK(hipSetDevice(h->cfg.device));
     CGCHK(forward(h, images_dev, false, 0, (int)num, 0, (int)num, 0.f, 0, st));
     HIPCHK(hipMemcpyAsync(logits_dev, h->logits, (size_t)num * h->K * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return CGPT_OK;
+}
+
+static cgpt_status encode_check(cgpt_handle h, const void* src, const void* out, int64_t num, const char* who) {
+    CGCHK(check_call(h, src, out, num, who));
+    if (h->cfg.mode != CGPT_MODE_ENCODE_IMG)
+        return cgpt_fail(CGPT_ERR_STATE, std::string(who) + ": the handle was not created with CGPT_MODE_ENCODE_IMG");
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_encode_img(cgpt_handle h, const float* images_dev, int64_t num, float* inputs_llama_dev, void* stream) {
+    CGCHK(encode_check(h, images_dev, inputs_llama_dev, num, "cgpt_encode_img"));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int64_t per = (int64_t)h->Q * h->PD, chw = (int64_t)3 * h->cfg.img_size * h->cfg.img_size;
+    for (int64_t done = 0; done < num; done += h->cfg.max_batch) {
+        const int nb = (int)((num - done < h->cfg.max_batch) ? (num - done) : h->cfg.max_batch);
+        CGCHK(forward(h, images_dev + done * chw, false, 0, nb, 0, nb, 0.f, 0, st, 0, 0, 0, inputs_llama_dev + done * per));
+    }
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_encode_img_noisy(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num, float sigma,
+                                  uint64_t noise_seed, float* inputs_llama_dev, void* stream) {
+    CGCHK(encode_check(h, x_dev, inputs_llama_dev, num, "cgpt_encode_img_noisy"));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int64_t per = (int64_t)h->Q * h->PD;
+    for (int64_t done = 0; done < num; done += h->cfg.max_batch) {
+        const int nb = (int)((num - done < h->cfg.max_batch) ? (num - done) : h->cfg.max_batch);
+        CGCHK(forward(h, x_dev, true, first_sample + done, nb, 0, nb, sigma, noise_seed, st, 0, 0, 0, inputs_llama_dev + done * per));
+    }
     return CGPT_OK;
 }
 

@@ -1,0 +1,155 @@
+"""MiniGPT4Classifier -- full MiniGPT-4 (`generate`) as the base classifier of `Smooth` (BASELINE configs[2]).
+
+Mirrors `MiniGPTBase.generate` (graphs/models/minigpt4/models/minigpt_base.py:374-448) and `get_context_emb` (:75-89):
+
+    encode_img(images)            -> libcgpt.so  (cgpt_encode_img / cgpt_encode_img_noisy: HIP noise + ViT-G + Q-Former +
+                                                  llama_proj straight into the buffer the LLM reads; minigpt4.py:121-149)
+    prompt splice + left padding  -> this file, PyTorch-ROCm tensors (minigpt_base.py:401-416)
+    llama_model.generate(...)     -> Hugging Face `generate` on PyTorch-ROCm, greedy, <= max_new_tokens (:418-431);
+                                     the LLM is a frozen decoder loaded BY LOCAL PATH by the caller (base_model.py:181-247) --
+                                     nothing is downloaded here
+    decode + clean-up             -> this file (:441-448)
+    answer -> class               -> agents/label_adapter.AnswerLabelMap (the "decoder-to-label" mapping, README.md:28-29)
+    argmax / vote histogram       -> libcgpt.so (cgpt_vote: wavefront arg-max + 64-bit atomics)
+
+The LLM decode is memory-bound PyTorch work and stays outside the MFMA-roofline claim; what this class adds
+for the Monte-Carlo loop is that the N noisy copies of one image share ONE text prompt: the prompt segments are tokenised and
+embedded once per call and broadcast, and because every row then has the same length there is no padding and the attention
+mask is all ones (identical to what the reference's left-padding produces for equal lengths).
+
+`Smooth` sees the engine interface (`sample_counts`), so noise generation stays fused into the patch-embed operand.
+"""
+import torch
+
+from .classifier import vote
+
+IMAGE_PLACEHOLDER = "<ImageHere>"
+
+
+def prepare_texts(questions):
+    """`MiniGPT4EvalAgent.prepare_texts` with CONV_VISION_minigptv2 (agents/minigpt4_eval_agent.py:265-271; conversation.py:130-137:
+    system "", roles ("<s>[INST] ", " [/INST]"), sep ""): one user turn, assistant turn left open."""
+    return ["<s>[INST] " + q + " [/INST]" for q in questions]
+
+
+def clean_answer(text: str) -> str:
+    """Post-processing of a decoded sequence, minigpt_base.py:444-447."""
+    text = text.split("</s>")[0]
+    text = text.replace("<s>", "")
+    return text.split(r"[/INST]")[-1].strip()
+
+
+class MiniGPT4Classifier:
+    """:param encoder: a `HipClassifier(mode="encode_img")` (or any object with `encode_img(images) -> (emb, atts)` and
+               `encode_img_noisy(x, first_sample, num, sigma, seed) -> emb`, emb = [B, queries, llm_hidden])
+       :param llama_model: a causal LM with `.generate(inputs_embeds=..., attention_mask=...)` and an input embedding table
+               (`get_input_embeddings()`), e.g. `LlamaForCausalLM.from_pretrained(<local path>, torch_dtype=torch.float16)`
+       :param llama_tokenizer: its tokenizer (`__call__(text, return_tensors="pt", add_special_tokens=...)`, `decode`)
+       :param prompt: the text every noisy copy is asked, containing one `<ImageHere>`
+       :param label_map: `AnswerLabelMap` -- frozen when torch.distributed is initialised (see label_adapter.py)
+    """
+
+    def __init__(self, encoder, llama_model, llama_tokenizer, prompt, label_map, max_new_tokens=20, max_batch=None,
+                 generate_kwargs=None):
+        self.encoder = encoder
+        self.llama_model = llama_model
+        self.llama_tokenizer = llama_tokenizer
+        self.prompt = prompt
+        self.label_map = label_map
+        self.num_classes = label_map.num_classes
+        self.max_new_tokens = int(max_new_tokens)
+        self.max_batch = int(max_batch or getattr(encoder, "max_batch", 16))
+        # the reference's fixed generation arguments, minigpt_base.py:379-388,418-431
+        self.generate_kwargs = dict(num_beams=1, min_length=1, top_p=0.9, repetition_penalty=1, length_penalty=1,
+                                    temperature=1, do_sample=False)
+        self.generate_kwargs.update(generate_kwargs or {})
+        self.last_answers = []
+
+    # ---- nn.Module-shaped surface used by Smooth (smoothing.py:42,71)
+    def eval(self):
+        if hasattr(self.llama_model, "eval"):
+            self.llama_model.eval()
+        return self
+
+    @property
+    def device(self):
+        return next(self.llama_model.parameters()).device
+
+    def embed_tokens(self, token_ids):
+        """minigpt_base.py:366-371 (the LoRA-wrapped variant resolves to the same table)."""
+        return self.llama_model.get_input_embeddings()(token_ids)
+
+    # ---- minigpt_base.py:75-89
+    def _segment_embeddings(self, prompt, device):
+        segs = prompt.split(IMAGE_PLACEHOLDER)
+        toks = [self.llama_tokenizer(seg, return_tensors="pt", add_special_tokens=(i == 0)).input_ids.to(device)
+                for i, seg in enumerate(segs)]                         # only add bos to the first seg
+        return [self.embed_tokens(t) for t in toks]
+
+    def get_context_emb(self, prompt, img_list):
+        seg_embs = self._segment_embeddings(prompt, img_list[0].device)
+        assert len(seg_embs) == len(img_list) + 1, "Unmatched numbers of image placeholders and images."
+        mixed = [emb for pair in zip(seg_embs[:-1], img_list) for emb in pair] + [seg_embs[-1]]
+        return torch.cat(mixed, dim=1)
+
+    # ---- minigpt_base.py:374-448 with encode_img's output given
+    @torch.no_grad()
+    def generate_from_embeds(self, img_embeds, texts):
+        """img_embeds [B, queries, hidden] (any float dtype) + one prompt per row (or ONE str shared by all rows) -> list[str]."""
+        dtype = self.embed_tokens(torch.zeros(1, 1, dtype=torch.long, device=img_embeds.device)).dtype
+        img_embeds = img_embeds.to(dtype)
+        B = img_embeds.shape[0]
+        if isinstance(texts, str) or len(set(texts)) == 1:
+            # shared prompt: segments embedded once and broadcast; equal lengths -> no padding, all-ones mask
+            prompt = texts if isinstance(texts, str) else texts[0]
+            segs = self._segment_embeddings(prompt, img_embeds.device)
+            assert len(segs) == 2, "Unmatched numbers of image placeholders and images."
+            embs = torch.cat([segs[0].expand(B, -1, -1), img_embeds, segs[1].expand(B, -1, -1)], dim=1)
+            attn_mask = torch.ones(embs.shape[:2], dtype=torch.int, device=embs.device)
+        else:
+            assert len(texts) == B
+            batch_embs = [self.get_context_emb(t, [img_embeds[i][None]]) for i, t in enumerate(texts)]
+            max_len = max(e.shape[1] for e in batch_embs)
+            embs = torch.zeros([B, max_len, batch_embs[0].shape[2]], dtype=dtype, device=img_embeds.device)
+            attn_mask = torch.zeros([B, max_len], dtype=torch.int, device=img_embeds.device)
+            for i, emb in enumerate(batch_embs):                       # left padding, minigpt_base.py:413-416
+                embs[i, -emb.shape[1]:] = emb[0]
+                attn_mask[i, -emb.shape[1]:] = 1
+        outputs = self.llama_model.generate(inputs_embeds=embs, attention_mask=attn_mask, max_new_tokens=self.max_new_tokens,
+                                            **self.generate_kwargs)
+        answers = []
+        for output_token in outputs:
+            if output_token[0] == 0:
+                output_token = output_token[1:]
+            answers.append(clean_answer(self.llama_tokenizer.decode(output_token, skip_special_tokens=True)))
+        return answers
+
+    @torch.no_grad()
+    def generate(self, images, texts, **_ignored):
+        """`MiniGPTBase.generate(images, texts, ...)` -> list[str] (generation arguments are fixed at construction)."""
+        img_embeds, _ = self.encoder.encode_img(images)
+        return self.generate_from_embeds(img_embeds, texts)
+
+    # ---- base classifier: [B,3,H,W] -> [B,num_classes] one-hot logits (smoothing.py:21,97)
+    def _logits(self, answers, device):
+        self.last_answers = answers
+        return self.label_map.one_hot_logits(answers, device)
+
+    def __call__(self, images):
+        out = []
+        for lo in range(0, images.shape[0], self.max_batch):
+            out.append(self._logits(self.generate(images[lo:lo + self.max_batch], self.prompt), images.device))
+        return torch.cat(out)
+
+    # ---- the `_sample_noise` engine (smoothing.py:81-99): noise fused into encode_img, vote in HIP
+    def sample_counts(self, x, first_sample, num, batch_size, sigma, seed, counts=None):
+        if counts is None:
+            counts = torch.zeros(self.num_classes, dtype=torch.int64, device=x.device)
+        bs = max(1, min(int(batch_size), self.max_batch))
+        done = 0
+        while done < num:
+            nb = min(bs, num - done)
+            emb = self.encoder.encode_img_noisy(x, first_sample + done, nb, float(sigma), int(seed))
+            vote(self._logits(self.generate_from_embeds(emb, self.prompt), x.device), counts)
+            done += nb
+        return counts

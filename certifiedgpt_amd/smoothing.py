@@ -45,7 +45,7 @@ class Smooth(object):
     ABSTAIN = -1  # smoothing.py:17
 
     def __init__(self, base_classifier, num_classes: int, sigma: float, seed: int = 0, process_group=None,
-                 device_stats: bool = False):
+                 device_stats: bool = False, non_certifiable=()):
         """
         :param base_classifier: an engine exposing `sample_counts(x, first_sample, num, batch_size, sigma, seed)`
                (certifiedgpt_amd.HipClassifier), or any callable mapping a [B,C,H,W] CUDA tensor to [B,num_classes]
@@ -55,6 +55,8 @@ class Smooth(object):
         :param device_stats: finish certify / predict on the GPU (cgpt_certify_device / cgpt_predict_device: wavefront
                arg-max, Clopper-Pearson bound, binomial test, Phi^-1 in float64) and copy back 16 bytes instead of the
                histograms; same float64 code as the host path
+        :param non_certifiable: class ids that are not classes of the certificate (the "other" bucket of an answer
+               vocabulary, agents/label_adapter.py): certify / predict return ABSTAIN when such a class comes out on top
         """
         self.base_classifier = base_classifier
         self.num_classes = num_classes
@@ -62,6 +64,7 @@ class Smooth(object):
         self.seed = int(seed)
         self.process_group = process_group
         self.device_stats = bool(device_stats)
+        self.non_certifiable = frozenset(int(c) for c in non_certifiable)
         self._next_sample = 0
         self._lib = _lib.lib()
 
@@ -74,11 +77,17 @@ class Smooth(object):
             # classifier batches and sum both histograms with ONE all-reduce.  Same sample indices as the two-call path.
             counts_selection, counts_estimation = self._sample_noise_pair(x, n0, n, batch_size)
             if counts_estimation is None:                  # device_stats: [2, K] int64 on the GPU
-                return self._finalize_device(counts_selection[0], counts_selection[1], n, alpha, predict=False)
+                return self._certifiable(self._finalize_device(counts_selection[0], counts_selection[1], n, alpha, predict=False))
         else:
             counts_selection = self._sample_noise(x, n0, batch_size)
             counts_estimation = self._sample_noise(x, n, batch_size)
-        return self.certify_from_counts(counts_selection, counts_estimation, n, alpha)
+        return self._certifiable(self.certify_from_counts(counts_selection, counts_estimation, n, alpha))
+
+    def _certifiable(self, result):
+        """(label, radius) -> (ABSTAIN, 0.0) when the label is one of the non-certifiable classes."""
+        if self.non_certifiable and result[0] in self.non_certifiable:
+            return Smooth.ABSTAIN, 0.0
+        return result
 
     def _sample_noise_pair(self, x, n0: int, n: int, batch_size):
         first = self._next_sample
@@ -122,7 +131,7 @@ class Smooth(object):
             import torch.distributed as dist
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
         c = counts.cpu().numpy().astype(int)
-        return [self.certify_from_counts(c[i, 0], c[i, 1], n, alpha) for i in range(G)]
+        return [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(G)]
 
     def sample_noise_many(self, xs, num: int, batch_size, common_noise: bool = True) -> np.ndarray:
         """`_sample_noise` for a stack of images -> int array [G, num_classes].  common_noise=True: every image sees the
@@ -151,13 +160,24 @@ class Smooth(object):
         return counts.cpu().numpy().astype(int)
 
     def predict(self, x: torch.tensor, n: int, alpha: float, batch_size: int) -> int:
-        """smoothing.py:58-79.  Returns the predicted class or ABSTAIN."""
+        """smoothing.py:58-79.  Returns the predicted class (a numpy.int64, as the reference's `top2[0]`) or ABSTAIN (int)."""
         self.base_classifier.eval()
+        if self.device_stats:
+            counts = self._sample_noise_device(x, n, batch_size)
+            if counts.is_cuda:                             # binomial test on the GPU: 16 bytes come back instead of the histogram
+                label = self._finalize_device(counts, counts, n, alpha, predict=True)
+                return self._predicted(label)
+            return self._predicted(self.predict_from_counts(counts.cpu().numpy().astype(int), alpha))
         counts = self._sample_noise(x, n, batch_size)
-        return self.predict_from_counts(counts, alpha)
+        return self._predicted(self.predict_from_counts(counts, alpha))
 
-    def _sample_noise(self, x: torch.tensor, num: int, batch_size) -> np.ndarray:
-        """smoothing.py:81-99 -> ndarray[int] of length num_classes with the per-class vote counts."""
+    def _predicted(self, label: int):
+        if label == Smooth.ABSTAIN or label in self.non_certifiable:
+            return Smooth.ABSTAIN                          # smoothing.py:77 returns the plain int constant
+        return np.int64(label)                             # smoothing.py:79 returns an element of an int64 ndarray
+
+    def _sample_noise_device(self, x: torch.tensor, num: int, batch_size) -> torch.Tensor:
+        """`_sample_noise` up to and including the all-reduce; the histogram stays where the classifier left it (the GPU)."""
         first = self._next_sample
         self._next_sample += num
         rank, world = _world(self.process_group)
@@ -167,7 +187,11 @@ class Smooth(object):
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)   # the one collective (C1)
-        return counts.cpu().numpy().astype(int)
+        return counts
+
+    def _sample_noise(self, x: torch.tensor, num: int, batch_size) -> np.ndarray:
+        """smoothing.py:81-99 -> ndarray[int] of length num_classes with the per-class vote counts."""
+        return self._sample_noise_device(x, num, batch_size).cpu().numpy().astype(int)
 
     def _count_arr(self, arr: np.ndarray, length: int) -> np.ndarray:
         """smoothing.py:101-105 (host histogram; the GPU path votes in the HIP kernel instead)."""

@@ -140,6 +140,17 @@ cgpt_status cgpt_forward_logits(cgpt_handle h, const float* x_dev, int64_t first
                                 float sigma, uint64_t noise_seed, float* logits_dev, void* stream);
 /* Run the classifier on caller-supplied images [num,3,H,W] float32 (no noise) -> logits [num,num_classes]. */
 cgpt_status cgpt_classify(cgpt_handle h, const float* images_dev, int64_t num, float* logits_dev, void* stream);
+/* MiniGPT4.encode_img (minigpt4.py:121-149) as a first-class product: ViT -> ln_vision -> Q-Former -> llama_proj for
+ * `num` caller-supplied images [num,3,H,W] float32, written to inputs_llama_dev [num, qf_queries, proj_dim] float32 -- the
+ * tensor MiniGPTBase.generate splices into the LLM prompt (minigpt_base.py:401-405; `atts_llama` is all ones, minigpt4.py:148,
+ * and is not materialised).  Any num >= 0 (internally cut into batches of max_batch); CGPT_MODE_ENCODE_IMG handles only
+ * (CGPT_ERR_STATE otherwise); no host sync.  The build-side label head is not evaluated. */
+cgpt_status cgpt_encode_img(cgpt_handle h, const float* images_dev, int64_t num, float* inputs_llama_dev, void* stream);
+/* The same for the Monte-Carlo draws of Smooth._sample_noise (smoothing.py:95-97 with a generating base classifier):
+ * row b of inputs_llama_dev is encode_img(x + sigma * eps_{first_sample + b}); the noise is generated inside the patch-embed
+ * operand as in cgpt_sample_counts, so the noisy images never exist in HBM. */
+cgpt_status cgpt_encode_img_noisy(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num, float sigma,
+                                  uint64_t noise_seed, float* inputs_llama_dev, void* stream);
 /* Intermediate activations of the last cgpt_forward_logits / cgpt_classify call, as float32, for parity tests:
  * what = "vit_out"   [num, T, vit_dim]   (VisionTransformer.forward_features output, eva_vit.py:349)
  *        "ln_vision" [num, T, vit_dim]   (CGPT_MODE_ENCODE_IMG only; minigpt4.py:129)

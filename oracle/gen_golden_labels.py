@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Golden vectors for the text->label normaliser: outputs of the REFERENCE's own VQA answer normaliser
 (common/vqa_tools/vqa_eval.py: the clean-up at :211-216, processPunctuation :249-259, processDigitArticle :261-274) on a list
-of answer strings that contain no contractions.  Build container only; only the JSON travels.
+of answer strings, among them every key of its contraction table (as a lone word and inside a sentence) and the contracted
+forms themselves.  Build container only; only the JSON travels.
 
     python oracle/gen_golden_labels.py
 """
@@ -19,6 +20,12 @@ ANSWERS = ["Yes", "no.", " A dog ", "the red car", "Two", "two dogs and a cat", 
            "on the left/right", "a man (standing)", "What?", "yes!", "an apple, a pear", "THE END", "ten people", "none",
            "zero", "skate-board", "tennis racket", "10", "he is 5 feet tall", "black & white", "pizza\nand fries", "a\tb",
            "one two three", "stop sign.", "U.S.A.", "2.", ".5", "green,blue", "frisbee?!", "left", "right side of the road"]
+
+ANSWERS += ["I dont know", "its not there, isnt it", "thats what shes doing", "Im sure Ive seen it", "somebody'd say so",
+            "theyre at 5 oclock", "yall come back", "he said: couldnt've", "whats that?", "don't", "it's"]
+ANSWERS += sorted(ev.contractions.keys())
+ANSWERS += ["the " + k + " thing" for k in sorted(ev.contractions.keys())[::7]]
+ANSWERS += sorted(set(ev.contractions.values()))
 
 out = []
 for a in ANSWERS:

@@ -88,3 +88,43 @@ def test_label_adapter_matches_reference_normaliser_goldens():
     assert [m(t) for t in ("Yes", "yes.", "No", "a cat", "the cat", "dog", "bird")] == [0, 0, 1, 2, 2, 3, 3]   # cap -> "other"
     logits = m.one_hot_logits(["yes", "no"])
     assert logits.shape == (2, 4) and logits[0, 0] == 1 and logits[1, 1] == 1
+
+
+def test_label_map_frozen_vocabulary_and_other_bucket():
+    from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
+    m = AnswerLabelMap(4, ["yes", "no"])                      # a vocabulary given up front freezes the map
+    assert m.frozen and m.other_id == 3
+    assert [m(t) for t in ("Yes.", "NO", "maybe", "a maybe")] == [0, 1, 3, 3] and m.answers == ["yes", "no"]
+    g = AnswerLabelMap(3)                                      # exploratory: grows, then overflows into "other"
+    assert [g(t) for t in ("b", "a", "b", "c")] == [0, 1, 0, 2] and not g.frozen
+    assert g.freeze()("zzz") == 2
+
+
+def test_checkpoint_with_wrong_names_is_an_error_not_a_silent_zero_model():
+    from certifiedgpt_amd.agents.minigpt4_certify_agent import prepare_state_dict
+    names = ["visual_encoder.cls_token", "visual_encoder.blocks.0.norm1.weight", "ln_vision.weight", "head.weight"]
+    full = {n: torch.zeros(1) for n in names}
+    out, missing = prepare_state_dict({"model": dict(full, **{"llama_model.x": torch.zeros(1)})}, names)     # BLIP-2 style wrapper
+    assert sorted(out) == sorted(names) and not missing
+    out, _ = prepare_state_dict({"model_state_dict": full}, names)
+    assert sorted(out) == sorted(names)
+    # raw EVA checkpoint: no "visual_encoder." prefix (eva_vit.py:445-456)
+    raw = {"cls_token": torch.zeros(1), "blocks.0.norm1.weight": torch.zeros(1), "ln_vision.weight": torch.zeros(1), "head.weight": torch.zeros(1)}
+    out, _ = prepare_state_dict(raw, names)
+    assert sorted(out) == sorted(names)
+    with pytest.raises(KeyError, match="missing"):
+        prepare_state_dict({"encoder.cls": torch.zeros(1), "ln_vision.weight": torch.zeros(1)}, names)
+    out, missing = prepare_state_dict({"ln_vision.weight": torch.zeros(1)}, names, allow_partial=True)
+    assert list(out) == ["ln_vision.weight"] and len(missing) == 3
+
+
+def test_smooth_abstains_on_non_certifiable_top_class():
+    from certifiedgpt_amd import Smooth
+    s = Smooth(Engine(), 5, 0.5, non_certifiable=(2,))        # class 2 wins 90 % of the votes but is the "other" bucket
+    assert s.certify(torch.zeros(3, 8, 8), 100, 100, 0.001, 50) == (Smooth.ABSTAIN, 0.0)
+    assert s.predict(torch.zeros(3, 8, 8), 100, 0.001, 50) == Smooth.ABSTAIN
+    t = Smooth(Engine(), 5, 0.5)
+    lab, rad = t.certify(torch.zeros(3, 8, 8), 100, 100, 0.001, 50)
+    assert lab == 2 and abs(rad - 0.3782577025559939) < 1e-9
+    p = t.predict(torch.zeros(3, 8, 8), 100, 0.001, 50)
+    assert p == 2 and isinstance(p, np.int64)                 # smoothing.py:79 returns an int64 ndarray element

@@ -162,3 +162,60 @@ def test_fused_certify_pass_matches_two_pass_single_and_two_ranks():
     # remainder to rank 1), i.e. 64 samples on both ranks
     assert got[0][2][-2:] == [(335, 26, 16), (386, 38, 16)]
     assert got[1][2][-2:] == [(361, 25, 16), (424, 39, 16)]
+
+
+# ------------------------------------------------------------------ text-generating classifier + answer vocabulary, 2 ranks
+class AnswerEngine:
+    """A generic callable classifier (Smooth's non-engine path is GPU-only, so this stand-in implements sample_counts itself):
+    the 'generated answer' of global sample i is one of a few strings whose ORDER OF FIRST APPEARANCE depends on where a
+    rank's shard starts -- exactly the situation in which a growing label map gives different ids on different ranks."""
+    ANSWERS = ["a red bus", "two dogs", "The Bus.", "dont know", "stop sign", "2 dogs"]
+
+    def __init__(self, label_map):
+        self.label_map = label_map
+
+    def eval(self):
+        return self
+
+    def sample_counts(self, x, first_sample, num, batch_size, sigma, seed):
+        idx = np.arange(first_sample, first_sample + num)
+        texts = [self.ANSWERS[(i * 7 + i // 3) % len(self.ANSWERS)] for i in idx]
+        ids = [self.label_map(t) for t in texts]
+        return torch.from_numpy(np.bincount(ids, minlength=self.label_map.num_classes).astype(np.int64))
+
+
+def _label_worker(rank, world, port, q):
+    from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = torch.zeros(3, 8, 8)
+        frozen = AnswerLabelMap(5, ["red bus", "2 dogs", "bus", "stop sign"])      # vocabulary up front -> frozen
+        counts = cg.Smooth(AnswerEngine(frozen), 5, 0.5)._sample_noise(x, 60, 16).tolist()
+        try:
+            cg.Smooth(AnswerEngine(AnswerLabelMap(5)), 5, 0.5)._sample_noise(x, 60, 16)
+            grew = "no error"
+        except RuntimeError as e:
+            grew = str(e)
+        q.put((rank, counts, grew))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_answer_vocabulary_is_rank_independent_and_growth_is_refused():
+    from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
+    frozen = AnswerLabelMap(5, ["red bus", "2 dogs", "bus", "stop sign"])
+    single = cg.Smooth(AnswerEngine(frozen), 5, 0.5)._sample_noise(torch.zeros(3, 8, 8), 60, 16).tolist()
+    assert sum(single) == 60 and single[4] > 0                      # "dont know" -> "don't know" -> other
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_label_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] == single                          # same ids on every rank: the all-reduce sums like with like
+    assert all("would grow under torch.distributed" in g[2] for g in got)

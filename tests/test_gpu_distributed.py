@@ -66,3 +66,73 @@ def test_two_ranks_on_one_gpu_match_single_process():
     # certify_many consumes the same sample indices as consecutive certify calls would: re-run from the same cursor
     import certifiedgpt_amd as cg  # noqa: F401
     assert len(single[3]) == 3 and all(isinstance(r[0], int) for r in single[3])
+
+
+def _nccl_run(rank, world, port, q):
+    """One rank per GPU over RCCL (backend "nccl" IS RCCL on ROCm): the all-reduce of the int64 vote histograms on xGMI."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import certifiedgpt_amd as cg
+    from oracle import model_oracle as mo
+    from gpu_util import make_classifier
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        K = 10
+        cfg = mo.tiny_config(mode=mo.MODE_ENCODE_IMG, num_classes=K)
+        clf = cg.HipClassifier(mode="encode_img", num_classes=K, max_batch=32, device=rank, vit_ln_eps=cfg.vit_ln_eps,
+                               ln_vision_eps=cfg.ln_vision_eps, qf_ln_eps=cfg.qf_ln_eps,
+                               **{k: getattr(cfg, k) for k in ("img_size", "patch_size", "vit_dim", "vit_depth", "vit_heads", "vit_mlp",
+                                                               "qf_layers", "qf_dim", "qf_heads", "qf_ffn", "qf_queries", "qf_xattn_freq", "proj_dim")})
+        clf.load_state_dict(mo.init_params(cfg, 20251121))
+        x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(f"cuda:{rank}")
+        s = cg.Smooth(clf, K, 0.25, seed=5)
+        out = (s.certify(x0, 25, 39, 0.05, 32), int(s.predict(x0, 30, 0.05, 7)), s._sample_noise(x0, 11, 4).tolist())
+        q.put((rank, out, dist.get_backend(), dist.get_world_size()))
+        clf.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (the driver's multi-GPU node); a one-GPU box skips")
+def test_two_ranks_two_gpus_rccl_match_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_run, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and got[0][2] == "nccl" and got[0][3] == 2
+    single = _launch(1)[0][1]
+    assert got[0][1][0] == single[0] and got[0][1][1] == int(single[1]) and got[0][1][2] == single[2]
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts its two ranks itself (a child `torch.distributed.run`) and reports
+    n_gpus = 2; on this one-GPU box as a rehearsal (both ranks on cuda:0, gloo), so rccl_ranks is 0 and says so.  A request for
+    more GPUs than the node has, outside the rehearsal, is refused with exit code 2 instead of measuring one GPU."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, CGPT_BENCH_ONE_GPU_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["collective_backend"] == "gloo" and line["rccl_ranks"] == 0
+    assert line["value"] > 0 and line["single_image_certify_ms"] > 0
+    if torch.cuda.device_count() < 8:
+        env.pop("CGPT_BENCH_ONE_GPU_REHEARSAL")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 2 and "refusing" in r.stderr
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

@@ -1,0 +1,166 @@
+"""End-to-end parity at BASELINE.json's full model size: whole `Smooth.certify` calls on the GPU (HIP path through the
+C-ABI) against the CPU oracle (oracle/smooth_oracle.py around oracle/model_oracle.py, the restatement of the reference's
+randomized_smoothing/smoothing.py:29-56 and eva_vit.py / Qformer.py / minigpt4.py:121-149) on IDENTICAL weights, image and
+noise draws (the GPU's own draws, exported).
+
+  * BASELINE configs[0]: Smooth.certify N=10, sigma=0.25 -- here on ViT-G + head and on the full-size encode_img classifier
+    (ViT-G + 12-layer Q-Former + llama_proj + head, "configs[2] minus the Vicuna decode").
+  * the headline sigma=0.5 draw: per-sample argmax agreement rate fp16-GPU vs fp32-CPU over 32 samples, and |dR| of the
+    certificates computed from the two histograms.
+
+Tolerances (written where used): a sample is DECISIVE when its fp32 top-2 logit margin exceeds MARGIN x max|logit|; decisive
+samples must vote identically, counts may differ by at most the number of non-decisive samples, (label, abstain) must be equal
+whenever every sample is decisive, and |dR| <= 1e-3 (north star) whenever the labels agree and the counts are equal.
+CPU cost: 20 + 32 ViT-G forwards (~25 s on the GPU box's 16 cores) + 22 full encode_img forwards (~12 s)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import certifiedgpt_amd as cg
+from oracle import model_oracle as mo, smooth_oracle as so
+from gpu_util import DEV, make_classifier, rel_err
+
+pytestmark = pytest.mark.gpu
+
+MARGIN = 1e-2          # fp32 top-2 margin, relative to max|logit|, above which fp16 may not flip the vote
+K = 1000
+
+
+def _cores():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def _device_params(clf, cfg):
+    """The weights exactly as the device computes with them (fp16-rounded matrices), as fp32 CPU tensors for the oracle."""
+    return {n: torch.from_numpy(clf.get_weight(n)).reshape(s) for n, s in mo.param_shapes(cfg).items()}
+
+
+def _certify_both(clf, cfg, params, x, n0, n, sigma, alpha, seed):
+    """(gpu (label, R), oracle (label, R), gpu counts [2,K], oracle counts [2,K], gpu logits, oracle logits)."""
+    torch.set_num_threads(_cores())
+    s = cg.Smooth(clf, K, sigma, seed=seed)
+    gpu_out = s.certify(x, n0, n, alpha, 10)
+    gpu_counts = clf.sample_counts_pair(x, 0, n0, n0, n, 10, sigma, seed).cpu().numpy()
+    gpu_logits = clf.forward_logits(x, 0, n0 + n, sigma, seed).cpu()
+    draws = cg.noise_batch(torch.zeros_like(x), 0, n0 + n, 1.0, seed).cpu().numpy()     # N(0,1) exactly as the GPU drew them
+    ref_logits = []
+
+    def classifier(batch):
+        out = mo.forward_all(params, torch.from_numpy(np.ascontiguousarray(batch)), cfg)["logits"]
+        ref_logits.append(out)
+        return out.numpy()
+
+    oracle = so.SmoothOracle(classifier, K, sigma, lambda first, num, shape: draws[first:first + num])
+    xc = x.cpu().numpy()
+    oracle._cursor = 0
+    o_sel = oracle._sample_noise(xc, n0, 10)
+    o_est = oracle._sample_noise(xc, n, 10)
+    ora_out = so.certify_from_counts(o_sel, o_est, n, alpha, sigma)
+    return gpu_out, ora_out, gpu_counts, np.stack([o_sel, o_est]), gpu_logits, torch.cat(ref_logits)
+
+
+def _check_certify(tag, gpu_out, ora_out, gpu_counts, ora_counts, gpu_logits, ref_logits, n, alpha, sigma):
+    top2 = ref_logits.topk(2, dim=1).values
+    decisive = (top2[:, 0] - top2[:, 1]) > MARGIN * ref_logits.abs().max()
+    agree = gpu_logits.argmax(1) == ref_logits.argmax(1)
+    err = rel_err(gpu_logits, ref_logits)
+    print(f"[{tag}] argmax agreement {int(agree.sum())}/{len(agree)}, decisive {int(decisive.sum())}/{len(agree)}, "
+          f"logits rel err {err:.2e}, gpu {gpu_out}, oracle {ora_out}")
+    assert err <= 2e-2, err
+    assert bool(agree[decisive].all()), (tag, "a decisive sample voted differently", int((~agree & decisive).sum()))
+    flips = int(np.abs(gpu_counts - ora_counts).sum()) // 2
+    assert flips <= int((~decisive).sum()), (tag, flips, int((~decisive).sum()))
+    assert gpu_counts.sum() == ora_counts.sum() == len(agree)
+    # the statistics on the GPU's own counts are exact (decision) / 1e-9 (radius) against the oracle's statistics
+    lab, rad = so.certify_from_counts(gpu_counts[0], gpu_counts[1], n, alpha, sigma)
+    assert gpu_out[0] == lab and abs(gpu_out[1] - rad) <= 1e-9
+    if bool(decisive.all()):
+        assert np.array_equal(gpu_counts, ora_counts)
+    if np.array_equal(gpu_counts, ora_counts):
+        assert gpu_out[0] == ora_out[0]                                   # label and abstain decision
+        assert abs(gpu_out[1] - ora_out[1]) <= 1e-3                       # north-star tolerance on R
+    return float(agree.float().mean())
+
+
+# ------------------------------------------------------------------ ViT-G + head (BASELINE configs[0] / [1] model)
+@pytest.fixture(scope="module")
+def vitg_pair():
+    cfg = mo.Config(mode=mo.MODE_VIT_HEAD, num_classes=K)
+    clf = make_classifier(cfg, max_batch=32)
+    clf.init_synthetic(seed=0)
+    params = _device_params(clf, cfg)
+    yield clf, cfg, params
+    clf.close()
+
+
+def test_vitg_config0_certify_matches_cpu_oracle(vitg_pair):
+    """BASELINE configs[0]: Smooth.certify(n0=10, n=10, sigma=0.25, alpha=0.001) end to end, GPU vs CPU oracle."""
+    clf, cfg, params = vitg_pair
+    x = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    out = _certify_both(clf, cfg, params, x, 10, 10, 0.25, 0.001, 42)
+    _check_certify("vitg config0", *out, 10, 0.001, 0.25)
+    # N=10 certifies only on a unanimous vote, with R = 0.25 * Phi^-1(0.001^(1/10)) (SURVEY.md 8c known answer)
+    if out[0][0] != cg.Smooth.ABSTAIN:
+        assert abs(out[0][1] - 0.0007439894428455479) <= 1e-9
+
+
+def test_vitg_headline_sigma_argmax_agreement_and_radius(vitg_pair):
+    """sigma = 0.5 (the headline noise level): 32 identical noisy samples through the fp16 GPU path and the fp32 oracle;
+    argmax agreement on decisive samples, and the radii that the two vote histograms certify (n = 32) within 1e-3 when the
+    histograms agree."""
+    clf, cfg, params = vitg_pair
+    torch.set_num_threads(_cores())
+    x = torch.from_numpy(mo.synthetic_image(cfg, seed=77)).to(DEV)
+    n, sigma, seed, alpha = 32, 0.5, 42, 0.001
+    noisy = cg.noise_batch(x, 0, n, sigma, seed)
+    gpu_logits = clf(noisy).cpu()
+    assert torch.equal(gpu_logits, clf.forward_logits(x, 0, n, sigma, seed).cpu())          # fused noise path, same bits
+    ref_logits = torch.cat([mo.forward_all(params, noisy[i:i + 8].cpu(), cfg)["logits"] for i in range(0, n, 8)])
+    g_cnt = np.bincount(gpu_logits.argmax(1).numpy(), minlength=K)
+    o_cnt = np.bincount(ref_logits.argmax(1).numpy(), minlength=K)
+    s = cg.Smooth(clf, K, sigma, seed=seed)
+    gpu_out = s.certify_from_counts(g_cnt, g_cnt, n, alpha)
+    ora_out = so.certify_from_counts(o_cnt, o_cnt, n, alpha, sigma)
+    rate = _check_certify("vitg sigma0.5", gpu_out, ora_out, np.stack([g_cnt, g_cnt]), np.stack([o_cnt, o_cnt]),
+                          torch.cat([gpu_logits, gpu_logits]), torch.cat([ref_logits, ref_logits]), n, alpha, sigma)
+    assert rate >= 0.9
+
+
+# ------------------------------------------------------------------ full-size encode_img (configs[2] minus the Vicuna decode)
+@pytest.fixture(scope="module")
+def encode_img_pair():
+    cfg = mo.Config(mode=mo.MODE_ENCODE_IMG, num_classes=K)               # ViT-G + 12-layer Q-Former (768, 32 queries) + llama_proj
+    clf = make_classifier(cfg, max_batch=20)
+    clf.init_synthetic(seed=0)
+    params = _device_params(clf, cfg)
+    yield clf, cfg, params
+    clf.close()
+
+
+def test_full_size_encode_img_stages_match_oracle(encode_img_pair):
+    """MiniGPT4.encode_img at full size (minigpt4.py:121-149; Qformer.py:402-474: 12 layers, 32x257 cross-attention in the even
+    ones): every stage of 2 noisy samples against the fp32 oracle."""
+    clf, cfg, params = encode_img_pair
+    torch.set_num_threads(_cores())
+    x = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    noisy = cg.noise_batch(x, 0, 2, 0.5, 42)
+    logits = clf(noisy).cpu()
+    ref = mo.forward_all(params, noisy.cpu(), cfg)
+    errs = {w: rel_err(clf.activation(w, 2), ref[w]) for w in ("vit_out", "ln_vision", "qformer", "llama")}
+    errs["logits"] = rel_err(logits, ref["logits"])
+    print("[encode_img full size] rel err per stage:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for w, tol in (("vit_out", 2e-2), ("ln_vision", 2e-2), ("qformer", 2e-2), ("llama", 2e-2), ("logits", 2e-2)):
+        assert errs[w] <= tol, (w, errs[w])
+    assert ref["llama"].shape == (2, 32, 4096)
+
+
+def test_full_size_encode_img_config0_certify_matches_cpu_oracle(encode_img_pair):
+    clf, cfg, params = encode_img_pair
+    x = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    out = _certify_both(clf, cfg, params, x, 10, 10, 0.25, 0.001, 42)
+    _check_certify("encode_img config0", *out, 10, 0.001, 0.25)

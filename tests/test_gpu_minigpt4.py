@@ -1,0 +1,117 @@
+"""GPU tests of the full-MiniGPT-4 path (BASELINE configs[2] shape on tiny dimensions): cgpt_encode_img / cgpt_encode_img_noisy
+(minigpt4.py:121-149 as a first-class C-ABI product) and `MiniGPT4Classifier` (minigpt_base.py:374-448) as the base classifier of
+`Smooth`, with a random-init tiny LlamaForCausalLM on PyTorch-ROCm standing in for the frozen Vicuna-7B (no weights in the
+container; nothing is downloaded) and token-id strings as answers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import certifiedgpt_amd as cg
+from certifiedgpt_amd import _lib
+from certifiedgpt_amd.minigpt4 import MiniGPT4Classifier, prepare_texts
+from certifiedgpt_amd.agents import registry, setup_agent
+from certifiedgpt_amd.agents import minigpt4_certify_agent  # noqa: F401
+from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
+from oracle import model_oracle as mo, smooth_oracle as so, generate_oracle as go
+from gpu_util import DEV, tiny_pair, rel_err
+from toy_llm import ToyTokenizer, tiny_llama
+
+pytestmark = pytest.mark.gpu
+PROMPT = prepare_texts(["<Img><ImageHere></Img> [vqa] what is shown here"])[0]
+
+
+def test_encode_img_entry_points_match_the_forward_and_the_oracle():
+    clf, p16, params, cfg = tiny_pair(mo.MODE_ENCODE_IMG, max_batch=4)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    noisy = cg.noise_batch(x0, 3, 4, 0.5, 42)
+    clf(noisy)
+    want = clf.activation("llama", 4)                                   # inputs_llama of the logits forward
+    emb, atts = clf.encode_img(noisy)
+    assert emb.shape == (4, cfg.qf_queries, cfg.proj_dim) and torch.equal(emb, want)
+    assert atts.shape == (4, cfg.qf_queries) and atts.dtype == torch.long and bool((atts == 1).all())   # minigpt4.py:148
+    assert rel_err(emb, mo.forward_all(p16, noisy.cpu(), cfg)["llama"]) <= 1e-2
+    assert torch.equal(clf.encode_img_noisy(x0, 3, 4, 0.5, 42), want)   # fused noise: same bits
+    # any num: more samples than max_batch are cut into batches internally; results do not depend on the cut
+    many = clf.encode_img_noisy(x0, 0, 11, 0.5, 42)
+    assert torch.equal(many[3:7], want) and torch.isfinite(many).all()
+    assert clf.encode_img_noisy(x0, 0, 0, 0.5, 42).shape[0] == 0
+    # a CGPT_MODE_VIT_HEAD handle has no Q-Former: CGPT_ERR_STATE, not a crash
+    vit, _, _, vcfg = tiny_pair(mo.MODE_VIT_HEAD, max_batch=4)
+    out = torch.empty(4, 8, 192, device=DEV)
+    rc = vit._L.cgpt_encode_img(vit._h, C.c_void_p(noisy.data_ptr()), 4, C.c_void_p(out.data_ptr()), None)
+    assert rc == 5 and b"CGPT_MODE_ENCODE_IMG" in vit._L.cgpt_last_error()
+
+
+@pytest.fixture(scope="module")
+def minigpt4():
+    enc, p16, params, cfg = tiny_pair(mo.MODE_ENCODE_IMG, max_batch=8)
+    llm = tiny_llama(hidden=cfg.proj_dim, dtype=torch.float16, device=DEV)     # frozen fp16 decoder, base_model.py:201-219
+    return enc, llm, cfg
+
+
+def _answers_by_oracle(enc, llm, x0, first, num, sigma, seed):
+    """Reference-shaped path: noisy images -> encode_img -> statement-by-statement generate restatement."""
+    noisy = cg.noise_batch(x0, first, num, sigma, seed)
+    emb, _ = enc.encode_img(noisy)
+    return go.generate(llm, ToyTokenizer(), emb.to(torch.float16), [PROMPT] * num, max_new_tokens=5)
+
+
+def test_generate_classifier_certify_matches_reference_shaped_path(minigpt4):
+    enc, llm, cfg = minigpt4
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    sigma, seed, n0, n, alpha = 0.25, 7, 16, 24, 0.05
+    ref_answers = _answers_by_oracle(enc, llm, x0, 0, n0 + n, sigma, seed)
+    vocab = sorted(set(ref_answers))[:5]
+    K = len(vocab) + 1
+    clf = MiniGPT4Classifier(enc, llm, ToyTokenizer(), PROMPT, AnswerLabelMap(K, vocab), max_new_tokens=5)
+    print("answers:", sorted(set(ref_answers)))
+    # one-hot logits of caller-supplied images == labels of the reference-shaped answers
+    noisy = cg.noise_batch(x0, 0, 8, sigma, seed)
+    lab = [vocab.index(a) if a in vocab else K - 1 for a in ref_answers]
+    assert clf(noisy).argmax(1).tolist() == lab[:8]
+    # Smooth through the engine path (noise fused into encode_img, vote in HIP)
+    s = cg.Smooth(clf, K, sigma, seed=seed, non_certifiable=(clf.label_map.other_id,))
+    c_sel = s._sample_noise(x0, n0, 8)
+    c_est = s._sample_noise(x0, n, 5)                                   # ragged batches
+    assert c_sel.tolist() == np.bincount(lab[:n0], minlength=K).tolist()
+    assert c_est.tolist() == np.bincount(lab[n0:], minlength=K).tolist()
+    s.reset()
+    got = s.certify(x0, n0, n, alpha, 8)
+    want = so.certify_from_counts(c_sel, c_est, n, alpha, sigma)
+    if want[0] == clf.label_map.other_id:
+        want = (cg.Smooth.ABSTAIN, 0.0)
+    assert got[0] == want[0] and abs(got[1] - want[1]) <= 1e-9
+    s.reset()
+    p = s.predict(x0, n0, alpha, 8)
+    wp = so.predict_from_counts(c_sel, alpha)
+    assert p == (cg.Smooth.ABSTAIN if wp == clf.label_map.other_id else wp)
+
+
+def test_certify_agent_drives_the_generating_classifier(minigpt4, tmp_path):
+    """`image_text_certify` (the plugin the reference leaves empty) end to end over full MiniGPT-4: HipClassifier encoder built
+    from the agent's config, decoder + tokenizer injected (a real run gives model.generate.llama_model = <local Vicuna dir>)."""
+    enc, llm, cfg = minigpt4
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    vocab = sorted(set(_answers_by_oracle(enc, llm, x0, 0, 12, 0.25, 0)))[:4]
+    dims = {k: getattr(cfg, k) for k in ("img_size", "patch_size", "vit_dim", "vit_depth", "vit_heads", "vit_mlp", "qf_layers",
+                                         "qf_dim", "qf_heads", "qf_ffn", "qf_queries", "qf_xattn_freq", "proj_dim")}
+    torch.save({"model": {k: v for k, v in mo.init_params(cfg, 20251121).items()}}, tmp_path / "ckpt.pth")
+    conf = {"run": {"agent": "image_text_certify", "output_dir": str(tmp_path), "seed": 0,
+                    "smoothing": {"sigma": 0.25, "n0": 8, "n": 16, "alpha": 0.05, "batch_size": 8, "num_classes": len(vocab) + 1,
+                                  "radii": [0.0, 0.1]}},
+            "model": {"dims": dims, "weights": str(tmp_path / "ckpt.pth"),
+                      "generate": {"prompt": PROMPT, "answers": vocab, "max_new_tokens": 5}},
+            "data": {"num_images": 2, "seed": 3}}
+    registry.register("configuration", conf)
+    agent = setup_agent(conf)
+    agent.tokenizer, agent.llama_model = ToyTokenizer(), llm
+    agent.run()
+    res = agent.finalize()
+    assert res["images"] == 2 and len(agent.records) == 2
+    assert isinstance(agent.model, MiniGPT4Classifier) and agent.model.label_map.frozen
+    for r in agent.records:
+        assert r["predict"] == cg.Smooth.ABSTAIN or 0 <= r["predict"] < len(vocab)      # "other" is never certified
+    lines = open(tmp_path / "certify.tsv").read().strip().splitlines()
+    assert len(lines) == 3

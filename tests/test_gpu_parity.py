@@ -225,7 +225,11 @@ def test_predict_and_n1000_sharded_125_per_gpu_match_single_pass():
         s.reset()
         got = s.predict(x0, 1000, alpha, 125)
         assert got == so.predict_from_counts(full.cpu().numpy(), alpha)
-        assert isinstance(got, int)
+        # return types of smoothing.py:77,79: the int constant ABSTAIN, else an element of an int64 ndarray
+        assert (got == cg.Smooth.ABSTAIN and type(got) is int) or isinstance(got, np.int64)
+        sd = cg.Smooth(clf, K, 0.25, seed=9, device_stats=True)          # binomial test on the GPU: same decision
+        got_dev = sd.predict(x0, 1000, alpha, 125)
+        assert got_dev == got and type(got_dev) is type(got)
     # certify at N=1000 through the fused pass == oracle statistics on the same counts
     s.reset()
     lab, rad = s.certify(x0, 1000, 1000, 0.001, 125)

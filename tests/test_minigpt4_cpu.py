@@ -1,0 +1,65 @@
+"""Host logic of the MiniGPT-4 `generate` base classifier (certifiedgpt_amd/minigpt4.py) on the CPU: prompt splice, left
+padding, greedy decode through a random-init tiny LlamaForCausalLM, decode clean-up, answer -> label -- against the
+statement-by-statement restatement of minigpt_base.py:75-89,374-448 in oracle/generate_oracle.py.  The encoder is a stub
+(encode_img needs the GPU); the GPU test tests/test_gpu_minigpt4.py runs the same classifier over cgpt_encode_img."""
+import torch
+
+from certifiedgpt_amd.minigpt4 import MiniGPT4Classifier, prepare_texts, clean_answer
+from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
+from oracle import generate_oracle as go
+from toy_llm import ToyTokenizer, StubEncoder, tiny_llama
+
+PROMPT = prepare_texts(["<Img><ImageHere></Img> [vqa] what is shown here"])[0]
+
+
+def _classifier(num_classes=8, vocabulary=()):
+    return MiniGPT4Classifier(StubEncoder(), tiny_llama(), ToyTokenizer(), PROMPT, AnswerLabelMap(num_classes, vocabulary),
+                              max_new_tokens=6)
+
+
+def test_prompt_template_and_cleanup():
+    assert PROMPT == "<s>[INST] <Img><ImageHere></Img> [vqa] what is shown here [/INST]"     # conversation.py:130-137
+    assert clean_answer("<s> [INST] q [/INST] a cat </s> junk") == "a cat"                   # minigpt_base.py:444-447
+    assert clean_answer("plain") == "plain"
+
+
+def test_shared_prompt_path_equals_reference_shaped_generate():
+    clf = _classifier()
+    images = torch.randn(5, 3, 8, 8)
+    emb, atts = clf.encoder.encode_img(images)
+    assert atts.shape == (5, 4) and bool((atts == 1).all())
+    ref = go.generate(clf.llama_model, clf.llama_tokenizer, emb, [PROMPT] * 5, max_new_tokens=6)
+    assert clf.generate_from_embeds(emb, PROMPT) == ref                 # segments embedded once and broadcast
+    assert clf.generate_from_embeds(emb, [PROMPT] * 5) == ref
+    assert clf.generate(images, PROMPT) == ref
+    assert all(isinstance(a, str) for a in ref) and len(set(ref)) >= 1
+
+
+def test_ragged_prompts_left_padding_equals_reference_shaped_generate():
+    clf = _classifier()
+    images = torch.randn(3, 3, 8, 8)
+    emb, _ = clf.encoder.encode_img(images)
+    texts = prepare_texts(["<ImageHere> short", "<Img><ImageHere></Img> a much longer question about the picture", "<ImageHere> mid size one"])
+    ref = go.generate(clf.llama_model, clf.llama_tokenizer, emb, texts, max_new_tokens=6)
+    assert clf.generate_from_embeds(emb, texts) == ref
+    # context embedding of one sample: bos only on the first segment, image tokens spliced at the placeholder
+    ctx = clf.get_context_emb(texts[0], [emb[0][None]])
+    tok = ToyTokenizer()
+    n0 = tok("<s>[INST]", add_special_tokens=True).input_ids.shape[1]
+    n1 = tok("short [/INST]", add_special_tokens=False).input_ids.shape[1]
+    assert ctx.shape == (1, n0 + 4 + n1, 64)
+    assert torch.equal(ctx[0, n0:n0 + 4], emb[0])
+
+
+def test_one_hot_logits_follow_the_frozen_vocabulary():
+    clf = _classifier()
+    images = torch.randn(6, 3, 8, 8)
+    answers = clf.generate(images, PROMPT)
+    vocab = sorted(set(answers))[:3]
+    clf2 = _classifier(num_classes=5, vocabulary=vocab)
+    assert clf2.label_map.frozen
+    logits = clf2(images)
+    assert logits.shape == (6, 5) and bool((logits.sum(1) == 1).all())
+    want = [vocab.index(a) if a in vocab else clf2.label_map.other_id for a in answers]
+    assert logits.argmax(1).tolist() == want
+    assert clf2.last_answers == answers[-len(clf2.last_answers):]

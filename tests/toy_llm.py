@@ -1,0 +1,71 @@
+"""A random-init tiny LlamaForCausalLM (transformers is importable; nothing is downloaded) and a toy word tokenizer with the
+tokenizer surface MiniGPTBase uses (`__call__(text, return_tensors="pt", add_special_tokens=...)`, `.input_ids`, `.to`,
+`decode(ids, skip_special_tokens=True)`): stand-ins for Vicuna-7B + LlamaTokenizer, which are not in the container."""
+import torch
+
+VOCAB = 96
+PAD, BOS, EOS = 0, 1, 2
+
+
+class _Encoding:
+    def __init__(self, ids):
+        self.input_ids = ids
+        self.attention_mask = torch.ones_like(ids)
+
+    def to(self, device):
+        self.input_ids = self.input_ids.to(device)
+        self.attention_mask = self.attention_mask.to(device)
+        return self
+
+
+class ToyTokenizer:
+    """Words -> ids by a stable hash into [3, VOCAB); id k decodes to the word f"w{k}" (token-id strings as answers)."""
+    pad_token_id, bos_token_id, eos_token_id = PAD, BOS, EOS
+
+    @staticmethod
+    def _word_id(w):
+        h = 0
+        for ch in w:
+            h = (h * 131 + ord(ch)) % 1000003
+        return 3 + h % (VOCAB - 3)
+
+    def __call__(self, text, return_tensors="pt", add_special_tokens=True, **_):
+        ids = [self._word_id(w) for w in text.split()]
+        if add_special_tokens:
+            ids = [BOS] + ids
+        return _Encoding(torch.tensor([ids], dtype=torch.long))
+
+    def decode(self, ids, skip_special_tokens=True):
+        out = []
+        for t in ids.tolist():
+            if t in (PAD, BOS):
+                if not skip_special_tokens:
+                    out.append("<s>" if t == BOS else "<pad>")
+            elif t == EOS:
+                out.append("</s>")                       # the reference splits on the literal stop sign, minigpt_base.py:445
+            else:
+                out.append(f"w{t}")
+        return " ".join(out)
+
+
+def tiny_llama(hidden=64, seed=0, dtype=torch.float32, device="cpu"):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(vocab_size=VOCAB, hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=2,
+                      num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=512, pad_token_id=PAD,
+                      bos_token_id=BOS, eos_token_id=EOS)
+    torch.manual_seed(seed)
+    return LlamaForCausalLM(cfg).to(device=device, dtype=dtype).eval()
+
+
+class StubEncoder:
+    """encode_img stand-in for CPU tests: a fixed random projection of the mean-pooled image to [B, queries, hidden]."""
+    max_batch = 8
+
+    def __init__(self, hidden=64, queries=4, seed=1):
+        g = torch.Generator().manual_seed(seed)
+        self.w = torch.randn(3, queries * hidden, generator=g)
+        self.q, self.h = queries, hidden
+
+    def encode_img(self, images):
+        emb = (images.mean(dim=(2, 3)) @ self.w).view(-1, self.q, self.h)
+        return emb, torch.ones(emb.shape[:-1], dtype=torch.long)
