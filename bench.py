@@ -52,12 +52,14 @@ def synthetic_images(count, device, img=224):
 
 
 def host_cores():
-    """The GPU box gives one GPU's share of the host; os.cpu_count() reports the whole machine."""
+    """Threads of the CPU leg.  The GPU box gives one GPU's share of the host (16 cores per GPU on this pool) while
+    os.cpu_count() / the affinity mask report the whole machine; oversubscribing the share makes the fp32 forward many times
+    slower, so the default is capped at 16 (CGPT_CPU_THREADS overrides; the count used is reported as `cores`)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    return max(1, min(cores, int(os.environ.get("CGPT_CPU_THREADS", "64"))))
+    return max(1, min(cores, int(os.environ.get("CGPT_CPU_THREADS", "16"))))
 
 
 def cpu_baseline_and_parity(clf, x):
@@ -263,6 +265,11 @@ def main():
         pass
 
     fc1_ms, fc1_flops, fc1_n = clf.profile_read(1)
+    by_kind = {}
+    for kind, name in ((2, "qkv"), (3, "proj"), (1, "fc1_gelu"), (4, "fc2")):
+        ms, fl, cnt = clf.profile_read(kind)
+        if cnt:
+            by_kind[name] = {"avg_launch_us": 1e3 * ms / cnt, "tflops": fl / (ms * 1e-3) / 1e12, "launches": cnt}
     all_ms, all_flops, all_n = clf.profile_read(0)
 
     # The reference-shaped call, outside the timed region: ONE Smooth.certify(x, n0, n, alpha, batch_size = n0 + n) per image
@@ -307,7 +314,8 @@ def main():
                          "launches": fc1_n, "avg_launch_ms": fc1_ms / max(fc1_n, 1),
                          "flop_per_launch": fc1_flops / max(fc1_n, 1),
                          "all_gemms": {"achieved": all_tflops, "frac": all_tflops / MFMA_PEAK_TFLOPS, "launches": all_n,
-                                       "total_ms": all_ms}},
+                                       "total_ms": all_ms},
+                         "vit_gemms": by_kind},
             "results_sample": [[int(l), float(r)] for l, r in results[-3:]],
             "single_image_certify_ms": single_ms,
             "single_image_certify_note": "one reference-shaped Smooth.certify(x, n0, n, alpha, batch_size=n0+n) per image, no grouping "

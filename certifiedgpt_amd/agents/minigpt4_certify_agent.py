@@ -161,7 +161,10 @@ def build_classifier(model_cfg, num_classes, max_batch, device_index, tokenizer=
         if partial:                                   # e.g. a pretrained encoder + the build-side head left synthetic
             clf.init_synthetic(seed=int(model_cfg.get("seed", 0)))
         state = torch.load(path, map_location="cpu", weights_only=True)
-        state, _ = prepare_state_dict(state, clf.weight_names(), allow_partial=partial)
+        # the build-side label head is not part of MiniGPT-4: a generating classifier never evaluates it (its classes are
+        # the answer vocabulary), so it is neither required from nor loaded out of the checkpoint
+        names = [n for n in clf.weight_names() if not (generating and n.startswith("head."))]
+        state, _ = prepare_state_dict(state, names, allow_partial=partial)
         clf.load_state_dict(state, strict=False)
     else:
         clf.init_synthetic(seed=int(model_cfg.get("seed", 0)))

@@ -552,14 +552,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         const int b_rd = NARROW ? b_rd_narrow : b_rd_wide;
         const int wcols = NARROW ? 48 : BN_ / WN;       // columns per wave
         const int ecol0 = ncol0;                        // first column of THIS tile (set_tile moves on during the last K-tile)
-        f32x4 bias4[TNv];
-        {
-            const int nb0 = ecol0 + wc * wcols + 4 * g;
-#pragma unroll
-            for (int j = 0; j < TNv; ++j) {
-                bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias && nb0 + j * 16 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + j * 16);
-            }
+        // bias of this wave's 64 (48) columns: ONE LDS-DMA request (4 bytes per lane) into a per-wave 256-byte LDS area, read back at
+        // the epilogue.  (Register loads here cost four dependent round trips per tile: the compiler guards each conditional
+        // load with its own `s_waitcnt vmcnt(0)`, which also drained the previous tile's stores; and the 16 values sat in VGPRs
+        // through the whole K loop.)  The request is retired by the K loop's own waits long before the epilogue.
+        float* bias_lds = reinterpret_cast<float*>(smem3 + 2 * STAGE) + wave * 64;
+        if (p.bias) {
+            const int bc = min(ecol0 + wc * wcols + lane, p.N - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + bc),
+                                             (__attribute__((address_space(3))) void*)bias_lds, 4, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -570,8 +571,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
 #endif
         // K-tile 0 of this tile has landed (requested during the previous tile's last K-tile); both halves aligned.  After an
         // LDS-path epilogue its 8 requests are older than that epilogue's 16 stores: a counted wait leaves the stores in flight
-        if (lds_stores && !(p.ablate & 1024)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (+1: the bias request just issued is the youngest entry of the queue)
+        if (lds_stores && !(p.ablate & 1024)) {
+            if (p.bias) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         CGPT_SLOT_END
         if (late) { CGPT_SLOT_END }                    // the late half enters one slot behind
@@ -627,9 +631,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
         const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
 
-#pragma unroll
-        for (int j = 0; j < TNv; ++j) asm volatile("" : "+v"(bias4[j]));
         if (next_tile && !early) { set_tile(t + gridDim.x); load_a(c & 1, 0); load_b(c & 1, 0); }
+        f32x4 bias4[TNv];
+        {
+            int el0;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el0));
+#pragma unroll
+            for (int j = 0; j < TNv; ++j)
+                bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(bias_lds + j * 16 + 4 * (el0 >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         const bool full = (etm + 1) * BM2 <= p.M && ecol0 + (NARROW ? 192 : BN_) <= p.N && !(p.ablate & 2);
         constexpr bool F16_OUT = EPI == EPI_F16 || EPI == EPI_F16_GELU;
         if (NARROW && !(F16_OUT && full && (p.ldo & 7) == 0 && !(p.ablate & 512))) {
@@ -750,7 +760,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
 
 template <int EPI, int NQ>
 hipError_t launch_v3(const GemmParams& p, hipStream_t stream) {
-    constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t);
+    constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t) + 8 * 64 * (int)sizeof(float);   // two stages + bias
     DeviceInfo di;
     if (hipError_t e = device_info(di); e != hipSuccess) return e;
     static bool configured[kMaxDevices] = {false};
@@ -1171,14 +1181,18 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     if (force == 9) return launch_v6_epi(epilogue, 0, p, stream);
     if (force == 10) return launch_v6_epi(epilogue, 1, p, stream);
     if (force == 11) return launch_v8_epi(epilogue, p, stream);
+    if (force == 12) return launch_v9_epi(epilogue, p, stream);
 #endif
-    if (force == 0 && p.M >= 1024) {
+    if ((force == 0 || force == 13) && p.M >= 1024) {
         // measured on MI355X (profiles/r01/gemm_variants.txt): the 256x256 direct-to-LDS tile with the phase-alternating
         // schedule wins on every ViT / Q-Former shape, also when N is not a multiple of 256 (weights are allocated with 256-row
         // padding) ... except when 256x256 tiles would leave more than half of the 256 CUs idle (the Q-Former's N = 768 linears
         // at M = 200 x 32 rows: 75 tiles): there the 256x128 tile is 25-35 % faster.
         const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         if (tiles256 <= 128 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
+#ifdef CGPT_LAB
+        if (force == 13) return launch_v9_epi(epilogue, p, stream);       // lab: v9 wherever the automatic choice is v3
+#endif
         return launch_v3_epi<4>(epilogue, p, stream);
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);

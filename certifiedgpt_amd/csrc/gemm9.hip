@@ -1,0 +1,362 @@
+// gemm9.hip -- 256 x 256 x 64 fp16 MFMA GEMM, quadrant-phased with a 1.5-K-tile LDS-DMA run-ahead.
+//
+// Same tile, LDS image, swizzle, transposed accumulators, persistent XCD-aware tile walk, 192-column last tiles and epilogues as
+// gemm3_f16_kernel (gemm.hip), different K loop.  What v3 loses (in-kernel stamps, profiles/r01/gemm_variants.txt: 2 510-2 580
+// cycles per K-tile against 2 048 of MFMA issue) is the LDS-DMA request issue: all eight 1-KiB requests of a K-tile sit in the
+// first two of its four L segments (4 + 4, ~60-100 cycles each), because with (k-step, M-half) phases every phase touches every
+// row of the stage, so K-tile t+1 can only be requested during K-tile t and has to be retired with vmcnt(0) at its end.
+//
+// Here a phase is one QUADRANT of the 128 x 64 wave tile over the whole K = 64 of the K-tile:
+//     q0 = (m0, n0)   reads A(m0) [8 fragments] and B(n0) [4]        m0 / m1 = first / second 64 rows of the wave tile
+//     q1 = (m0, n1)   reads B(n1) [4]              (A(m0) kept)       n0 / n1 = first / second 32 columns (2 / 1 tiles of 16
+//     q2 = (m1, n1)   reads A(m1) [8]              (B(n1) kept)                 when the tile is a 192-column one)
+//     q3 = (m1, n0)   reads nothing                (A(m1), B(n0) kept)
+// so the four PARTS of a stage -- A(m0), B(n0), B(n1), A(m1): 16 KiB = two requests per wave each -- are last read in phases
+// q0, q0, q1, q2 and may be re-requested right after: in phase q1 / q2 / q3 of K-tile c the waves request A(m0) / B(n0) / B(n1) of
+// K-tile c+2 (same stage) and in q0 of K-tile c+1 its A(m1).  Two requests per phase instead of 4 + 4 + 0 + 0, issued after the
+// phase's fragment reads (the read latency hides the issue), and every part has >= 6 phases = 1.5 K-tiles to land.  Requests are
+// retired by a COUNTED wait -- the five younger parts stay in flight: s_waitcnt vmcnt(10), never 0 in steady state -- at the end
+// of the L segment before the one that first reads the part (then a barrier, as in v3; the two halves of the workgroup still run
+// one slot apart: L | barrier | M | barrier with the partner wave of the SIMD in the other kind of segment).
+//
+// LDS: two 64-KiB stages + 32 KiB of epilogue scratch (4 KiB per wave) = all 160 KiB.  The scratch is separate because both
+// stages have requests in flight during an epilogue.  The two halves are re-aligned for the epilogue (as in v3), so that the
+// two waves of a SIMD share its VALU during it.
+// The bias of a wave's 64 columns travels by one 4-byte-per-lane LDS-DMA request into its scratch at tile start.
+#include "gemm_common.h"
+
+namespace cgpt {
+
+namespace {
+
+#ifdef CGPT_PLAIN_STORES
+#define CGPT9_STORE16(v, ptr) (*(ptr) = (v))
+#else
+#define CGPT9_STORE16(v, ptr) __builtin_nontemporal_store((v), (ptr))
+#endif
+
+constexpr int kMaxDevices9 = 64;
+template <int V> struct IntTag9 { static constexpr int value = V; };
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
+    constexpr int BM2 = 256, BN_ = 256;
+    constexpr int A_ELEMS = BM2 * BK, STAGE = 2 * A_ELEMS;                 // halfs: A image then W image, 128-byte rows
+    extern __shared__ __attribute__((aligned(16))) half_t smem9[];
+    half_t* const scratch_all = smem9 + 2 * STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const bool late = wave >= 4;                                           // the half that runs one slot behind
+    const int r15 = lane & 15, g = lane >> 4;
+
+    const int tiles_m = (p.M + BM2 - 1) / BM2;
+    const int tiles_n = (p.N + BN_ - 1) / BN_;
+    const int ntiles = tiles_m * tiles_n;
+    const int nk = p.K / BK;
+    const bool split_n = (p.N % 256) == 128 && p.N >= 384 && !(p.ablate & 16384);
+
+    // ------------------------------------------------------------------ request side (runs ~1.5 K-tiles ahead of the MFMAs)
+    // piece i (0, 1) of this wave covers part rows 16*wave + 8*i + (lane>>3); source 16-byte chunk swizzled per row (as v3)
+    const int lr = lane >> 3, cpos = lane & 7;
+    const half_t* src_a0[2];   // A(m0): tile rows (wave>>2)*128 +  0 + 16*(wave&3) + 8*i + lr
+    const half_t* src_a1[2];   // A(m1):                        + 64
+    const half_t* src_b0[2];   // B(n0): W rows (wave>>1)*64 + 16*(wave&1) + 8*i + lr          (narrow: (wave>>1)*48 + ...)
+    const half_t* src_b1[2];   // B(n1):                    + 32                               (narrow: one piece, (wave>>1)*48 + 32 + 8*(wave&1) + lr)
+    int dst_a0, dst_a1, dst_b0[2], dst_b1[2];                               // LDS offsets (halfs) inside a stage, piece 0 (A: piece 1 = + 8 rows)
+    int rt = blockIdx.x, rkt = 0, rc = 0;                                   // request cursor: tile, K-tile in it, stream K-tile counter
+    bool req_ok = rt < ntiles;
+    auto set_req_tile = [&](int t) {
+        int tm, tn;
+        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn, p.group_m);
+        const bool narrow = split_n && tn >= tiles_n - 2;
+        const int ncol0 = narrow ? (tiles_n - 2) * BN_ + (tn - (tiles_n - 2)) * 192 : tn * BN_;
+        const int ra = (wave >> 2) * 128 + 16 * (wave & 3);
+        dst_a0 = ra * BK;
+        dst_a1 = (ra + 64) * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r0 = ra + 8 * i + lr, r1 = r0 + 64;
+            src_a0[i] = p.A + (int64_t)(tm * BM2 + r0) * p.lda + ((cpos ^ ((r0 >> 1) & 7)) << 3);
+            src_a1[i] = p.A + (int64_t)(tm * BM2 + r1) * p.lda + ((cpos ^ ((r1 >> 1) & 7)) << 3);
+            // W rows of the two B parts (LDS row == row inside the tile's W image)
+            const int b0 = narrow ? (wave >> 1) * 48 + 16 * (wave & 1) + 8 * i : (wave >> 1) * 64 + 16 * (wave & 1) + 8 * i;
+            const int b1 = narrow ? (wave >> 1) * 48 + 32 + 8 * (wave & 1) : b0 + 32;   // narrow: both pieces are the same 8 rows (idempotent)
+            dst_b0[i] = A_ELEMS + b0 * BK;
+            dst_b1[i] = A_ELEMS + b1 * BK;
+            src_b0[i] = p.W + (int64_t)(ncol0 + b0 + lr) * p.ldw + ((cpos ^ (((b0 + lr) >> 1) & 7)) << 3);
+            src_b1[i] = p.W + (int64_t)(ncol0 + b1 + lr) * p.ldw + ((cpos ^ (((b1 + lr) >> 1) & 7)) << 3);
+        }
+    };
+    auto glds = [&](const half_t* src, int lds_off) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem9 + lds_off), 16, 0, 0);
+    };
+    // PART: 0 = A(m0), 1 = B(n0), 2 = B(n1), 3 = A(m1); the four parts of one K-tile are requested consecutively in this order
+    auto request = [&](auto part_tag) __attribute__((always_inline)) {
+        constexpr int PART = decltype(part_tag)::value;
+        if (!req_ok) return;
+        const int sbase = (rc & 1) * STAGE;
+        const int koff = rkt * BK;
+        if constexpr (PART == 0) { glds(src_a0[0] + koff, sbase + dst_a0); glds(src_a0[1] + koff, sbase + dst_a0 + 8 * BK); }
+        if constexpr (PART == 1) { glds(src_b0[0] + koff, sbase + dst_b0[0]); glds(src_b0[1] + koff, sbase + dst_b0[1]); }
+        if constexpr (PART == 2) { glds(src_b1[0] + koff, sbase + dst_b1[0]); glds(src_b1[1] + koff, sbase + dst_b1[1]); }
+        if constexpr (PART == 3) {
+            glds(src_a1[0] + koff, sbase + dst_a1); glds(src_a1[1] + koff, sbase + dst_a1 + 8 * BK);
+            ++rc;                                                           // K-tile complete: advance the cursor
+            if (++rkt == nk) {
+                rkt = 0;
+                rt += gridDim.x;
+                req_ok = rt < ntiles;
+                if (req_ok) set_req_tile(rt);
+            }
+        }
+    };
+    // retire every request older than the five youngest parts; once the request stream has ended the count no longer holds.
+    // The 16 stores of an LDS-path epilogue and the bias request of the next tile sit in the same in-order queue: for the first
+    // four waits after such an epilogue they are younger than the part waited for, so the count grows by them and the stores
+    // stay in flight (any other epilogue: the plain count, which then also waits for its stores -- correct, slower).
+    int fresh = 0;
+    auto retire = [&]() __attribute__((always_inline)) {
+        if (!req_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (fresh > 0) {
+            --fresh;
+            if (p.bias) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    };
+
+    // ------------------------------------------------------------------ compute side
+    const int sw = (r15 >> 1) & 7;
+    const int k_off0 = ((g ^ sw) << 3), k_off1 = (((4 + g) ^ sw) << 3);
+    const int a_rd = (wr * 128 + r15) * BK;
+    const int b_rd_wide = A_ELEMS + (wc * 64 + r15) * BK, b_rd_narrow = A_ELEMS + (wc * 48 + r15) * BK;
+
+    f32x4 acc[8][4];
+    f16x8 af[4][2], bf0[2][2], bf1[2][2];
+#define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
+#define CGPT_SLOT_END CGPT_FENCE __builtin_amdgcn_s_barrier(); CGPT_FENCE
+
+    int c = 0;                                                              // stream K-tile counter of the compute side
+    int t = blockIdx.x;
+    if (req_ok) {
+        set_req_tile(rt);
+        // prime the stream: all of K-tile 0 and the first three parts of K-tile 1 (phase q0 of K-tile 0 then requests A(m1) of 1)
+        request(IntTag9<0>{}); request(IntTag9<1>{}); request(IntTag9<2>{}); request(IntTag9<3>{});
+        request(IntTag9<0>{}); request(IntTag9<1>{}); request(IntTag9<2>{});
+    }
+    half_t* const scr = scratch_all + wave * 2048;                          // 4 KiB of epilogue scratch per wave
+    float* const bias_lds = reinterpret_cast<float*>(scr);
+    // K-tile 0 of the first tile: A(m0), B(n0) landed for every wave (five younger parts in flight, as in steady state)
+    retire();
+    CGPT_SLOT_END
+
+    auto tile_body = [&](auto tnv_tag, int tm, int ncol0) __attribute__((always_inline)) {
+        constexpr int TNv = decltype(tnv_tag)::value;                       // column tiles of 16 per wave: 4, or 3 (192-column tile)
+        constexpr bool NARROW = TNv == 3;
+        constexpr int N1 = TNv - 2;                                         // column tiles of the n1 half
+        const int b_rd = NARROW ? b_rd_narrow : b_rd_wide;
+        const int wcols = NARROW ? 48 : 64;
+        if (p.bias) {                                                       // 64 bias values of this wave -> its scratch
+            const int bc = min(ncol0 + wc * wcols + lane, p.N - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + bc),
+                                             (__attribute__((address_space(3))) void*)bias_lds, 4, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < TNv; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (late) { CGPT_SLOT_END }                                         // the late half enters one slot behind
+
+        for (int kt = 0; kt < nk; ++kt, ++c) {
+            const half_t* st = smem9 + (c & 1) * STAGE;
+            // ---------------- q0 = (m0, n0)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf0[j][0] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + k_off0);
+                bf0[j][1] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + k_off1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK + k_off0);
+                af[i][1] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK + k_off1);
+            }
+            CGPT_FENCE
+            request(IntTag9<3>{});                                          // A(m1) of K-tile c+1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            retire();                                                       // B(n1) of this K-tile has landed (read in L(q1))
+            CGPT_SLOT_END
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+            CGPT_SLOT_END
+            // ---------------- q1 = (m0, n1)
+#pragma unroll
+            for (int j = 0; j < N1; ++j) {
+                bf1[j][0] = *reinterpret_cast<const f16x8*>(st + b_rd + (2 + j) * 16 * BK + k_off0);
+                bf1[j][1] = *reinterpret_cast<const f16x8*>(st + b_rd + (2 + j) * 16 * BK + k_off1);
+            }
+            CGPT_FENCE
+            request(IntTag9<0>{});                                          // A(m0) of K-tile c+2
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            retire();                                                       // A(m1) of this K-tile has landed (read in L(q2))
+            CGPT_SLOT_END
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < N1; ++j)
+                        acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[j][ks], af[i][ks], acc[i][2 + j], 0, 0, 0);
+            CGPT_SLOT_END
+            // ---------------- q2 = (m1, n1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *reinterpret_cast<const f16x8*>(st + a_rd + (4 + i) * 16 * BK + k_off0);
+                af[i][1] = *reinterpret_cast<const f16x8*>(st + a_rd + (4 + i) * 16 * BK + k_off1);
+            }
+            CGPT_FENCE
+            request(IntTag9<1>{});                                          // B(n0) of K-tile c+2
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            CGPT_SLOT_END
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < N1; ++j)
+                        acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[j][ks], af[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+            CGPT_SLOT_END
+            // ---------------- q3 = (m1, n0)
+            request(IntTag9<2>{});                                          // B(n1) of K-tile c+2
+            retire();                                                       // A(m0), B(n0) of K-tile c+1 have landed (read in its L(q0))
+            CGPT_SLOT_END
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], acc[4 + i][j], 0, 0, 0);
+            CGPT_SLOT_END
+        }
+
+        // the early half waits one slot for its partners' last M: both waves of a SIMD then run their epilogues TOGETHER (one wave
+        // alone issues VALU at half the SIMD's rate: with the halves left one slot apart the two epilogues ran one after the other,
+        // fc1 + GELU 1 001 -> 1 102 us per launch in the model)
+        if (!late) { CGPT_SLOT_END }
+        // ------------------------------------------------------------ epilogue
+        int el;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));   // lane id, not kept across the K loop
+        const int e15 = el & 15, eg = el >> 4;
+        if (nk < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // too few K-tiles for the counted waits to have retired the bias request
+        f32x4 bias4[TNv];
+#pragma unroll
+        for (int j = 0; j < TNv; ++j)
+            bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(bias_lds + j * 16 + 4 * eg) : f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // before the first pass overwrites the scratch
+        const bool full = (tm + 1) * BM2 <= p.M && ncol0 + (NARROW ? 192 : BN_) <= p.N;
+        constexpr bool F16_OUT = EPI == EPI_F16 || EPI == EPI_F16_GELU;
+        if (F16_OUT && full && (p.ldo & 7) == 0 && !(p.ablate & 512)) {
+            // fp16 output of a full tile, transposed through the wave's 4-KiB scratch: four passes of 32 rows x 64 columns; rows are
+            // 128 B with the 16-byte chunk index XOR-swizzled by row & 7; a lane then stores 16 contiguous bytes, 8 lanes one line
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            half_t* outp = reinterpret_cast<half_t*>(p.out);
+            const int row_rd = el >> 3, ch_rd = el & 7;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = ps * 2 + ii;
+                    const int row = ii * 16 + e15;
+#pragma unroll
+                    for (int jj = 0; jj < TNv; ++jj) {
+                        f32x4 v = acc[i][jj] + bias4[jj];
+                        if constexpr (EPI == EPI_F16_GELU) v = gelu_erf4(v);
+                        const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        const int ch = (jj * 2 + (eg >> 1)) ^ (row & 7);
+                        *reinterpret_cast<f16x4*>(scr + row * 64 + ch * 8 + (eg & 1) * 4) = hv;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // same wave wrote what it now reads
+                half_t* dst0 = outp + ((int64_t)tm * BM2 + wr * 128 + ps * 32 + row_rd) * p.ldo + ncol0 + wc * wcols + ch_rd * 8;
+                const int64_t step = 8 * p.ldo;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + row_rd;
+                    if (!NARROW || ch_rd < 6) {
+                        const f16x8 o = *reinterpret_cast<const f16x8*>(scr + row * 64 + ((ch_rd ^ (row & 7)) * 8));
+                        CGPT9_STORE16(o, reinterpret_cast<f16x8*>(dst0 + it * step));
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // reads returned before the next pass overwrites
+            }
+            fresh = (t + (int)gridDim.x < ntiles) ? 4 : 0;                  // only a following tile issues the bias request counted above
+        } else {
+            if constexpr (NARROW) {
+                f32x4 accn[8][3];
+#pragma unroll
+                for (int i2 = 0; i2 < 8; ++i2)
+#pragma unroll
+                    for (int j2 = 0; j2 < 3; ++j2) accn[i2][j2] = acc[i2][j2];
+                gemm_epilogue_256<EPI, 8, 3>(p, accn, bias4, tm * BM2 + wr * 128 + e15, ncol0 + wc * 48 + 4 * eg, full);
+            } else {
+                gemm_epilogue_256<EPI, 8, 4>(p, acc, bias4, tm * BM2 + wr * 128 + e15, ncol0 + wc * 64 + 4 * eg, full);
+            }
+        }
+    };
+
+    for (; t < ntiles; t += gridDim.x) {
+        int tm, tn;
+        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn, p.group_m);
+        const bool narrow = split_n && tn >= tiles_n - 2;
+        const int ncol0 = narrow ? (tiles_n - 2) * BN_ + (tn - (tiles_n - 2)) * 192 : tn * BN_;
+        if (narrow) tile_body(IntTag9<3>{}, tm, ncol0);
+        else tile_body(IntTag9<4>{}, tm, ncol0);
+    }
+#undef CGPT_FENCE
+#undef CGPT_SLOT_END
+}
+
+template <int EPI>
+hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t) + 32768;   // two stages + epilogue scratch = 160 KiB
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices9) return hipErrorInvalidDevice;
+    static bool configured[kMaxDevices9] = {false};
+    static int cus[kMaxDevices9] = {0};
+    if (!configured[dev]) {
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm9_f16_kernel<EPI>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); e != hipSuccess) return e;
+        int n = 0;
+        if (hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+        cus[dev] = n > 0 ? n : 256;
+        configured[dev] = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int grid = tiles < cus[dev] ? tiles : cus[dev];                   // one 512-thread workgroup per CU (LDS-limited), persistent
+    hipLaunchKernelGGL((gemm9_f16_kernel<EPI>), dim3(grid), dim3(512), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
+    switch (epilogue) {
+        case EPI_F16: return launch_v9<EPI_F16>(p, stream);
+        case EPI_F16_GELU: return launch_v9<EPI_F16_GELU>(p, stream);
+        case EPI_F32: return launch_v9<EPI_F32>(p, stream);
+        case EPI_RESID: return launch_v9<EPI_RESID>(p, stream);
+        case EPI_PATCH: return launch_v9<EPI_PATCH>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace cgpt

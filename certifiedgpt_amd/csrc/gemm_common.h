@@ -15,37 +15,38 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GROUP_M = 8;
 
 // Exact-erf GELU (nn.GELU default, eva_vit.py:50,61) = x * Phi(x).  The fc1 epilogue runs 128 of these per lane with the matrix
-// pipe idle (one workgroup per CU: both waves of a SIMD reach the epilogue together), so the VALU op count is what matters:
-//   1 - Phi(|x|) = 0.5 (1 + c1 u + ... + c7 u^7)^-16,  u = -|x|/2
-// -- the form of Abramowitz-Stegun 7.1.28 (one reciprocal and four squarings instead of exp AND reciprocal), degree 7, coefficients
-// fitted for |x| * error, i.e. the error of GELU itself: <= 6e-8 in exact arithmetic, <= 3.6e-7 evaluated in fp32, 0.1 % relative in
-// the tail -4.2 < x < -3 (fp16 output resolution is 5e-4 relative).  (A&S 7.1.26, used before: 3.3e-7 / 0.06 %, two transcendentals.)
-// gelu_erf2 evaluates two values with v_pk_fma_f32 / v_pk_mul_f32 (IEEE per component); every epilogue path goes through it, so a
-// value depends on nothing but the element.  Per element: 42 issue cycles instead of 58.
-#define CGPT_GELU_C1 -0.09973713755607605f
-#define CGPT_GELU_C2 0.08452103286981583f
-#define CGPT_GELU_C3 -0.026464305818080902f
-#define CGPT_GELU_C4 -4.3827335503010545e-06f
-#define CGPT_GELU_C5 -0.002318566432222724f
-#define CGPT_GELU_C6 -9.743619011715055e-05f
-#define CGPT_GELU_C7 -9.806572779780254e-05f
+// pipe idle (both waves of a SIMD reach the epilogue together and share its VALU: in-kernel stamps, 11-15 k of a tile's 73 k
+// cycles), so the VALU op count is what matters.  With t = |x|:
+//     gelu(x) = max(x, 0) - t * (1 - Phi(t)),        1 - Phi(t) = 2^Q(t),   Q = log2 of the upper normal tail,
+// Q is smooth (-1 - 1.15 t - 0.46 t^2 ... -> -t^2/2 log2 e), so a degree-7 polynomial fitted for t * |error of 2^Q| -- the error
+// of GELU itself -- is enough: <= 2.7e-7 evaluated in fp32 (fp32 resolution at |x| = 4 is 2.4e-7), 0.05 % relative in the tail
+// -4.2 < x < -3 (fp16 output resolution is 5e-4 relative), and Q(t) <= -29.9 for every t > 6 up to overflow (negative leading
+// coefficient), so large inputs give exactly max(x, 0).  Per pair of values: 2 v_and (|x|), 7 v_pk_fma_f32, 2 v_exp_f32,
+// 2 v_max_f32, 1 v_pk_fma_f32 = 14 instructions; the form used before -- 1 - Phi = 0.5 (1 + c1 u + ... + c7 u^7)^-16, u = -t/2, i.e.
+// the same degree plus a reciprocal AND four squarings (Abramowitz-Stegun 7.1.28) -- took 18 at the same accuracy (3.6e-7 / 0.1 %).
+// gelu_erf2 evaluates two values with v_pk_fma_f32 (IEEE per component); every epilogue path goes through it, so a value depends
+// on nothing but the element.
+#define CGPT_GELU_Q0 -9.999910593e-01f
+#define CGPT_GELU_Q1 -1.151225209e+00f
+#define CGPT_GELU_Q2 -4.586824775e-01f
+#define CGPT_GELU_Q3 -5.356145650e-02f
+#define CGPT_GELU_Q4 8.207941428e-03f
+#define CGPT_GELU_Q5 -8.253850974e-04f
+#define CGPT_GELU_Q6 4.516868648e-05f
+#define CGPT_GELU_Q7 -9.805353329e-07f
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-    const f32x2 u = {fabsf(x[0]) * -0.5f, fabsf(x[1]) * -0.5f};
+    const f32x2 t = {fabsf(x[0]), fabsf(x[1])};
     auto k = [](float v) { return f32x2{v, v}; };
-    f32x2 q = __builtin_elementwise_fma(u, k(CGPT_GELU_C7), k(CGPT_GELU_C6));
-    q = __builtin_elementwise_fma(q, u, k(CGPT_GELU_C5));
-    q = __builtin_elementwise_fma(q, u, k(CGPT_GELU_C4));
-    q = __builtin_elementwise_fma(q, u, k(CGPT_GELU_C3));
-    q = __builtin_elementwise_fma(q, u, k(CGPT_GELU_C2));
-    q = __builtin_elementwise_fma(q, u, k(CGPT_GELU_C1));
-    q = __builtin_elementwise_fma(q, u, k(1.0f));
-    f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
-    r = r * r;
-    r = r * r;
-    r = r * r;
-    r = r * r;
-    return __builtin_elementwise_fma(u, r, f32x2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)});
+    f32x2 q = __builtin_elementwise_fma(t, k(CGPT_GELU_Q7), k(CGPT_GELU_Q6));
+    q = __builtin_elementwise_fma(q, t, k(CGPT_GELU_Q5));
+    q = __builtin_elementwise_fma(q, t, k(CGPT_GELU_Q4));
+    q = __builtin_elementwise_fma(q, t, k(CGPT_GELU_Q3));
+    q = __builtin_elementwise_fma(q, t, k(CGPT_GELU_Q2));
+    q = __builtin_elementwise_fma(q, t, k(CGPT_GELU_Q1));
+    q = __builtin_elementwise_fma(q, t, k(CGPT_GELU_Q0));
+    const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    return __builtin_elementwise_fma(-t, e, f32x2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)});
 }
 // One value: the same arithmetic, result rounded to fp32 before anything else happens to it.  A plain fmaf version is not bit-identical
 // once its result is converted to fp16: the compiler fuses the last fma with the conversion (v_fma_mix: one rounding), the packed

@@ -34,6 +34,7 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
 #ifdef CGPT_LAB
 hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);   // gemm6.hip: 4-wave 128x128 wave tiles
 hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // gemm8.hip: two 4-wave workgroups per CU, 128x256 tiles
+hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // gemm9.hip: quadrant phases, 1.5-K-tile LDS-DMA run-ahead
 #endif
 extern int g_gemm_ablate;
 extern int g_gemm_group_m;

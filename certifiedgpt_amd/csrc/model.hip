@@ -344,14 +344,14 @@ cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_s
         const VitLayer& L = m->vit[i];
         HIPCHK(launch_layernorm(m->resid, D, i ? m->delta : nullptr, Dk, L.n1w, L.n1b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st,
                                 nullptr, 0, /*keep_x=*/1));
-        CGCHK(gemm(m, EPI_F16, m->xn, Dk, L.Wqkv, Dk, L.bqkv, m->qkv, m->ld_qkv, nullptr, 0, M, 3 * D, Dk, 0, st));
+        CGCHK(gemm(m, EPI_F16, m->xn, Dk, L.Wqkv, Dk, L.bqkv, m->qkv, m->ld_qkv, nullptr, 0, M, 3 * D, Dk, 2, st));
         CGCHK(attention(m->qkv, m->ld_qkv, (int64_t)T * m->ld_qkv, m->qkv + D, m->ld_qkv, m->qkv + 2 * D, m->ld_qkv,
                         (int64_t)T * m->ld_qkv, m->attn, Dk, (int64_t)T * Dk, nb, c.vit_heads, hd, T, T, st));
-        CGCHK(gemm(m, EPI_F16, m->attn, Dk, L.Wproj, Dk, L.bproj, m->delta2, Dk, nullptr, 0, M, D, Dk, 0, st));
+        CGCHK(gemm(m, EPI_F16, m->attn, Dk, L.Wproj, Dk, L.bproj, m->delta2, Dk, nullptr, 0, M, D, Dk, 3, st));
         HIPCHK(launch_layernorm(m->resid, D, i ? m->delta : nullptr, Dk, L.n2w, L.n2b, c.vit_ln_eps, m->xn, Dk, nullptr, 0, M, D, st,
                                 m->delta2, Dk, 0));
         CGCHK(gemm(m, EPI_F16_GELU, m->xn, Dk, L.Wfc1, Dk, L.bfc1, m->hid, m->mlp_k, nullptr, 0, M, m->mlp, Dk, 1, st));
-        CGCHK(gemm(m, EPI_F16, m->hid, m->mlp_k, L.Wfc2, m->mlp_k, L.bfc2, m->delta, Dk, nullptr, 0, M, D, m->mlp_k, 0, st));
+        CGCHK(gemm(m, EPI_F16, m->hid, m->mlp_k, L.Wfc2, m->mlp_k, L.bfc2, m->delta, Dk, nullptr, 0, M, D, m->mlp_k, 4, st));
     }
     if (c.mode == CGPT_MODE_VIT_HEAD) {
         // ln_vision on the CLS rows only (row stride T*D), applying the last block's pending update to those rows on the way
@@ -721,7 +721,7 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
     const std::string k(key);
     if (k == "gemm_kernel") {
 #ifdef CGPT_LAB
-        const bool ok = value >= 0 && value <= 11;
+        const bool ok = value >= 0 && value <= 13;
 #else
         const bool ok = value == 0 || value == 1 || value == 3 || value == 4;
 #endif

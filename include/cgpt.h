@@ -196,7 +196,8 @@ double cgpt_norm_ppf(double p);
 
 /* ---- measurement hooks (bench.py roofline) ----
  * When enabled, every GEMM launch is bracketed by HIP events on the launch stream; totals are read back with
- * cgpt_profile_read (which synchronises those events).  kind: 0 = all GEMMs, 1 = fc1 (GELU epilogue) GEMMs only. */
+ * cgpt_profile_read (which synchronises those events).  kind: 0 = all GEMMs (reading it drains the log), 1 = the ViT MLP fc1
+ * (GELU epilogue) GEMMs only, 2 = ViT qkv, 3 = ViT attention proj, 4 = ViT MLP fc2. */
 cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on);
 cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
 

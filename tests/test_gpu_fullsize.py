@@ -13,6 +13,7 @@ samples must vote identically, counts may differ by at most the number of non-de
 whenever every sample is decisive, and |dR| <= 1e-3 (north star) whenever the labels agree and the counts are equal.
 CPU cost: 20 + 32 ViT-G forwards (~25 s on the GPU box's 16 cores) + 22 full encode_img forwards (~12 s)."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -29,10 +30,13 @@ K = 1000
 
 
 def _cores():
+    """Threads for the CPU oracle: the GPU box's CPU share is 16 cores per GPU (its affinity mask / cpu_count report the whole
+    host; oversubscribing the share makes the fp32 forward many times slower).  CGPT_CPU_THREADS overrides."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("CGPT_CPU_THREADS", "16"))))
 
 
 def _device_params(clf, cfg):
@@ -51,7 +55,9 @@ def _certify_both(clf, cfg, params, x, n0, n, sigma, alpha, seed):
     ref_logits = []
 
     def classifier(batch):
+        t0 = time.perf_counter()
         out = mo.forward_all(params, torch.from_numpy(np.ascontiguousarray(batch)), cfg)["logits"]
+        print(f"  cpu oracle forward of {len(batch)} samples: {time.perf_counter() - t0:.1f} s ({torch.get_num_threads()} threads)", flush=True)
         ref_logits.append(out)
         return out.numpy()
 
@@ -120,7 +126,12 @@ def test_vitg_headline_sigma_argmax_agreement_and_radius(vitg_pair):
     noisy = cg.noise_batch(x, 0, n, sigma, seed)
     gpu_logits = clf(noisy).cpu()
     assert torch.equal(gpu_logits, clf.forward_logits(x, 0, n, sigma, seed).cpu())          # fused noise path, same bits
-    ref_logits = torch.cat([mo.forward_all(params, noisy[i:i + 8].cpu(), cfg)["logits"] for i in range(0, n, 8)])
+    ref_logits = []
+    for i in range(0, n, 8):
+        t0 = time.perf_counter()
+        ref_logits.append(mo.forward_all(params, noisy[i:i + 8].cpu(), cfg)["logits"])
+        print(f"  cpu oracle forward of 8 samples: {time.perf_counter() - t0:.1f} s", flush=True)
+    ref_logits = torch.cat(ref_logits)
     g_cnt = np.bincount(gpu_logits.argmax(1).numpy(), minlength=K)
     o_cnt = np.bincount(ref_logits.argmax(1).numpy(), minlength=K)
     s = cg.Smooth(clf, K, sigma, seed=seed)

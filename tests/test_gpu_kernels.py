@@ -19,9 +19,9 @@ def _gemm_kernels():
     """Kernel overrides this build of libcgpt.so accepts (results are identical for every one): the product library has the
     automatic choice (0), the 128x128 kernel (1), the 256x128 (3) and the 256x256 phased kernel (4); `make LAB=1` adds 2, 5..11."""
     L = cg.lib()
-    lab = L.cgpt_set_option(b"gemm_kernel", 11) == 0
+    lab = L.cgpt_set_option(b"gemm_kernel", 12) == 0
     L.cgpt_set_option(b"gemm_kernel", 0)
-    return list(range(12)) if lab else [0, 1, 3, 4]
+    return list(range(13)) if lab else [0, 1, 3, 4]
 
 
 GEMM_KERNELS = _gemm_kernels()

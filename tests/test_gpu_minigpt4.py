@@ -61,7 +61,7 @@ def _answers_by_oracle(enc, llm, x0, first, num, sigma, seed):
 def test_generate_classifier_certify_matches_reference_shaped_path(minigpt4):
     enc, llm, cfg = minigpt4
     x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
-    sigma, seed, n0, n, alpha = 0.25, 7, 16, 24, 0.05
+    sigma, seed, n0, n, alpha = 2.0, 7, 16, 24, 0.05          # a large sigma, so that the toy decoder's answers vary
     ref_answers = _answers_by_oracle(enc, llm, x0, 0, n0 + n, sigma, seed)
     vocab = sorted(set(ref_answers))[:5]
     K = len(vocab) + 1
@@ -94,12 +94,12 @@ def test_certify_agent_drives_the_generating_classifier(minigpt4, tmp_path):
     from the agent's config, decoder + tokenizer injected (a real run gives model.generate.llama_model = <local Vicuna dir>)."""
     enc, llm, cfg = minigpt4
     x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
-    vocab = sorted(set(_answers_by_oracle(enc, llm, x0, 0, 12, 0.25, 0)))[:4]
+    vocab = sorted(set(_answers_by_oracle(enc, llm, x0, 0, 12, 2.0, 0)))[:4]
     dims = {k: getattr(cfg, k) for k in ("img_size", "patch_size", "vit_dim", "vit_depth", "vit_heads", "vit_mlp", "qf_layers",
                                          "qf_dim", "qf_heads", "qf_ffn", "qf_queries", "qf_xattn_freq", "proj_dim")}
     torch.save({"model": {k: v for k, v in mo.init_params(cfg, 20251121).items()}}, tmp_path / "ckpt.pth")
     conf = {"run": {"agent": "image_text_certify", "output_dir": str(tmp_path), "seed": 0,
-                    "smoothing": {"sigma": 0.25, "n0": 8, "n": 16, "alpha": 0.05, "batch_size": 8, "num_classes": len(vocab) + 1,
+                    "smoothing": {"sigma": 2.0, "n0": 8, "n": 16, "alpha": 0.05, "batch_size": 8, "num_classes": len(vocab) + 1,
                                   "radii": [0.0, 0.1]}},
             "model": {"dims": dims, "weights": str(tmp_path / "ckpt.pth"),
                       "generate": {"prompt": PROMPT, "answers": vocab, "max_new_tokens": 5}},

@@ -200,7 +200,7 @@ def test_vitg_matches_oracle_on_two_samples(vitg):
     logits = clf(noisy).cpu()
     vit_gpu = clf.activation("vit_out", 2).cpu()
     params = {n: torch.from_numpy(clf.get_weight(n)).reshape(s) for n, s in mo.param_shapes(cfg).items()}
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("CGPT_CPU_THREADS", "16"))))   # the box's CPU share
     ref = mo.forward_all(params, noisy.cpu(), cfg)
     e_vit = rel_err(vit_gpu, ref["vit_out"])
     e_log = rel_err(logits, ref["logits"])
