@@ -543,22 +543,32 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     }
 }
 
+
+// per-device launch state (one handle per device, possibly several devices per process)
+constexpr int kMaxDevicesA = 64;
+inline hipError_t device_cus(int& dev, int& cus) {
+    static int table[kMaxDevicesA] = {0};
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevicesA) return hipErrorInvalidDevice;
+    if (table[dev] == 0) {
+        int n = 0;
+        if (hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+        table[dev] = n > 0 ? n : 256;
+    }
+    cus = table[dev];
+    return hipSuccess;
+}
+
 template <int HD, int DPAD>
 hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
     constexpr int lds_bytes = 18 * 16 * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_stream_kernel<HD, DPAD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int dev = 0, num_cus = 0;
+    if (hipError_t e = device_cus(dev, num_cus); e != hipSuccess) return e;
+    static bool configured[kMaxDevicesA] = {false};
+    if (!configured[dev]) {
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_stream_kernel<HD, DPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            e != hipSuccess) return e;
+        configured[dev] = true;
     }
     const int items = p.heads * p.B * ((p.Tq + 127) / 128);
     int grid = items < num_cus ? items : num_cus;
@@ -572,19 +582,13 @@ hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
 template <int HD, int DPAD, int NKT, int NT>
 hipError_t launch_one(const AttnParams& p, hipStream_t stream) {
     constexpr int lds_bytes = NKT * 16 * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
-    static bool configured = false;   // per instantiation; the attribute is idempotent
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, DPAD, NKT, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int dev = 0, num_cus = 0;
+    if (hipError_t e = device_cus(dev, num_cus); e != hipSuccess) return e;
+    static bool configured[kMaxDevicesA] = {false};
+    if (!configured[dev]) {
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, DPAD, NKT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            e != hipSuccess) return e;
+        configured[dev] = true;
     }
     const int items = p.heads * p.B;
     const int per_cu = lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 40 * 1024 ? 2 : 4);     // resident workgroups per CU (LDS)

@@ -9,6 +9,7 @@
 //              LayerNorm output / attention output [nb*T][D] fp16, qkv [nb*T][3D] fp16, MLP hidden [nb*T][6144] fp16, ...
 //              Row counts are padded to 256 and K-dims to 64 so every GEMM tile load is in bounds; pad columns
 //              are zero at allocation and never written.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <map>
@@ -698,6 +699,27 @@ cgpt_status cgpt_rgf_step(const float* x_adv_dev, const float* x_clean_dev, int6
 cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes, int64_t* counts_dev, void* stream) {
     if (!logits_dev || !counts_dev || num < 0 || num_classes < 1) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_vote: bad argument");
     HIPCHK(launch_vote(logits_dev, num_classes, num, num_classes, counts_dev, num, counts_dev, (hipStream_t)stream));
+    return CGPT_OK;
+}
+
+// The one collective of the path: sum the int64 vote histograms of all ranks in place.  RCCL is not linked into
+// this library: ncclAllReduce is taken from the process when the caller (who created the communicator) has RCCL loaded, else from
+// librccl.so.  ncclInt64 = 4, ncclSum = 0 (rccl.h).
+cgpt_status cgpt_allreduce_counts(void* rccl_comm, int64_t* counts_dev, int64_t count, void* stream) {
+    if (!rccl_comm || !counts_dev || count < 1) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_allreduce_counts: bad argument");
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    if (!fn) {
+        fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!fn) {
+            void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (lib) fn = (allreduce_fn)dlsym(lib, "ncclAllReduce");
+        }
+        if (!fn) return cgpt_fail(CGPT_ERR_STATE, "cgpt_allreduce_counts: ncclAllReduce not found (is RCCL installed?)");
+    }
+    const int rc = fn(counts_dev, counts_dev, (size_t)count, /*ncclInt64*/ 4, /*ncclSum*/ 0, rccl_comm, (hipStream_t)stream);
+    if (rc != 0) return cgpt_fail(CGPT_ERR_HIP, "cgpt_allreduce_counts: ncclAllReduce returned " + std::to_string(rc));
     return CGPT_OK;
 }
 

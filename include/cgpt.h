@@ -174,6 +174,14 @@ cgpt_status cgpt_rgf_step(const float* x_adv_dev, const float* x_clean_dev, int6
 /* smoothing.py:97-98,101-105: counts_dev[argmax(logits[b,:])] += 1 for b < num (first max index on ties). */
 cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes, int64_t* counts_dev, void* stream);
 
+/* ---- the one collective of the path, for callers that are not Python (Python callers use torch.distributed, whose "nccl"
+ *      backend IS RCCL on ROCm): in-place sum over all ranks of the int64 vote histograms a cgpt_sample_counts* call produced
+ *      on each rank's shard of the sample range -- ncclAllReduce(counts, counts, count, ncclInt64, ncclSum, comm, stream) over
+ *      xGMI.  rccl_comm is the caller's ncclComm_t (one process per GPU); count = num_classes for one histogram, or
+ *      num_images * 2 * num_classes for the table of cgpt_sample_counts_images.  Enqueued on `stream`, no host sync.
+ *      (The reference has no call site: its collectives are torch_xla's) ---- */
+cgpt_status cgpt_allreduce_counts(void* rccl_comm, int64_t* counts_dev, int64_t count, void* stream);
+
 /* ---- statistics: pure host functions, float64, no device needed ----
  * Smooth.certify lines 46-56 given the two histograms (smoothing.py:44,48). */
 cgpt_status cgpt_certify_from_counts(const int64_t* counts_selection, const int64_t* counts_estimation,

@@ -113,6 +113,16 @@ def test_bad_arguments_return_status_not_crash():
     assert L.cgpt_destroy(None) == 0
 
 
+def test_allreduce_counts_rejects_bad_arguments_without_touching_rccl():
+    """The C-level collective (include/cgpt.h): argument errors are status codes; a real all-reduce needs >= 2 GPUs (driver)."""
+    L = cg.lib()
+    assert L.cgpt_allreduce_counts(None, None, 10, None) == 1
+    assert b"cgpt_allreduce_counts" in L.cgpt_last_error()
+    buf = (C.c_int64 * 4)()
+    assert L.cgpt_allreduce_counts(None, C.cast(buf, C.c_void_p), 4, None) == 1      # null communicator
+    assert L.cgpt_allreduce_counts(C.cast(buf, C.c_void_p), C.cast(buf, C.c_void_p), 0, None) == 1   # empty histogram
+
+
 def test_shard_range_partitions_exactly():
     for num in (0, 1, 7, 10, 100, 125, 1000):
         for world in (1, 2, 3, 4, 8):

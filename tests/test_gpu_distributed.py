@@ -136,3 +136,44 @@ def test_bench_self_launches_its_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_c_level_allreduce_counts_single_rank_communicator():
+    """cgpt_allreduce_counts (the C-ABI form of the vote all-reduce, for callers without torch.distributed) on a real RCCL
+    communicator.  One GPU gives a one-rank communicator (sum over one rank = identity), which still exercises symbol
+    resolution, the ncclInt64 / ncclSum constants, the stream argument and in-place operation; the multi-rank sum is RCCL's."""
+    import ctypes as C
+    import glob
+    import certifiedgpt_amd as cg
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["/opt/rocm/lib/librccl.so"]
+    rccl = None
+    for path in cands:
+        try:
+            rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)          # global: cgpt_allreduce_counts must use the SAME RCCL instance
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no librccl.so found")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda:0")                          # HIP context
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        counts = torch.arange(2000, dtype=torch.int64, device="cuda:0") * 3 - 7
+        want = counts.clone()
+        L = cg.lib()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = L.cgpt_allreduce_counts(comm, C.c_void_p(counts.data_ptr()), counts.numel(), st)
+        assert rc == 0, L.cgpt_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(counts, want)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
