@@ -1172,6 +1172,7 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     const int force = vec_ok ? g_gemm_kernel : 1;   // 0 auto, 1 = 128x128 register-staged, 3 = 256x128 direct-to-LDS, 4 = 256x256 phased
     if (force == 3 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
     if (force == 4) return launch_v3_epi<4>(epilogue, p, stream);
+    if (force == 14) return launch_v9_epi(epilogue, p, stream, true);
 #ifdef CGPT_LAB
     if (force == 2) return launch_v2_epi<256>(epilogue, p, stream);
     if (force == 5) return launch_v3_epi<2>(epilogue, p, stream);
@@ -1181,9 +1182,9 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     if (force == 9) return launch_v6_epi(epilogue, 0, p, stream);
     if (force == 10) return launch_v6_epi(epilogue, 1, p, stream);
     if (force == 11) return launch_v8_epi(epilogue, p, stream);
-    if (force == 12) return launch_v9_epi(epilogue, p, stream);
+    if (force == 12) return launch_v9_epi(epilogue, p, stream, false);
 #endif
-    if ((force == 0 || force == 13) && p.M >= 1024) {
+    if ((force == 0 || force == 13 || force == 15) && p.M >= 1024) {
         // measured on MI355X (profiles/r01/gemm_variants.txt): the 256x256 direct-to-LDS tile with the phase-alternating
         // schedule wins on every ViT / Q-Former shape, also when N is not a multiple of 256 (weights are allocated with 256-row
         // padding) ... except when 256x256 tiles would leave more than half of the 256 CUs idle (the Q-Former's N = 768 linears
@@ -1191,8 +1192,12 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
         const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         if (tiles256 <= 128 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
 #ifdef CGPT_LAB
-        if (force == 13) return launch_v9_epi(epilogue, p, stream);       // lab: v9 wherever the automatic choice is v3
+        if (force == 13) return launch_v9_epi(epilogue, p, stream, false);   // lab: v9 wherever the automatic choice is v3
+        if (force == 15) return launch_v9_epi(epilogue, p, stream, true);    // lab: the two-phase quadrant kernel likewise
 #endif
+        // long K (ViT MLP fc2: K = 6144, 96 K-tiles per output tile): the two-phase quadrant kernel (gemm9.hip) -- its K loop is
+        // ~5 % faster in the model (fc2 905 -> 861 us per launch), its tile boundaries slower (fc1, 22 K-tiles per tile: 986 -> 1 017)
+        if (p.K >= 3072) return launch_v9_epi(epilogue, p, stream, true);
         return launch_v3_epi<4>(epilogue, p, stream);
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);

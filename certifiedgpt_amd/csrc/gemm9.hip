@@ -38,7 +38,18 @@ namespace {
 constexpr int kMaxDevices9 = 64;
 template <int V> struct IntTag9 { static constexpr int value = V; };
 
-template <int EPI>
+// PH2 = true ("v10"): TWO phases per K-tile instead of four -- P0 = quadrants q0 + q1 (32 MFMAs), P1 = q2 + q3 -- i.e. half the
+// barriers and L segments that fit the partner's 512-cycle M segment.  Model behind it (it reproduces the stamped cycle counts of
+// v3 with and without loads, of v3's two-phase form without loads and of v9: a fragment read costs ~16 cycles of a CU's LDS
+// pipe with four waves reading, + ~170 cycles of latency per L segment, an LDS-DMA request ~25, a barrier ~25): with 16-MFMA
+// phases (256 cycles) every L segment that holds 8 or 12 reads overruns its slot; with 32-MFMA phases L(P0) = 12 reads + 4
+// requests and L(P1) = 8 reads + 4 requests both fit.  v3's own two-phase form loses because all eight requests of a K-tile
+// fall into one L segment and the second half of a K-tile has no time to land; here the parts are requested as in v9:
+//     L(P1) of K-tile c:   A(m0), B(n0) of K-tile c+2          L(P0) of K-tile c+1:   B(n1), A(m1) of K-tile c+2
+// B(n1)'s four fragment reads are issued at the START of M(P0) (they complete under q0's 16 MFMAs), which keeps L(P0) at 12 reads.
+// Waits: end of L(P0) and of L(P1): vmcnt(8) (four younger parts stay in flight); the late half, whose partner reads B(n1) one
+// slot earlier than it does itself, also retires its share of the next K-tile's B(n1) at the end of M(P1): vmcnt(6).
+template <int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     constexpr int BM2 = 256, BN_ = 256;
     constexpr int A_ELEMS = BM2 * BK, STAGE = 2 * A_ELEMS;                 // halfs: A image then W image, 128-byte rows
@@ -119,7 +130,14 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     // four waits after such an epilogue they are younger than the part waited for, so the count grows by them and the stores
     // stay in flight (any other epilogue: the plain count, which then also waits for its stores -- correct, slower).
     int fresh = 0;
+    auto retire2 = [&](auto n_tag) __attribute__((always_inline)) {          // two-phase form: plain counts
+        constexpr int NP = decltype(n_tag)::value;
+        if (!req_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    };
     auto retire = [&]() __attribute__((always_inline)) {
+        if constexpr (PH2) { retire2(IntTag9<8>{}); return; }
         if (!req_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (fresh > 0) {
             --fresh;
@@ -145,14 +163,20 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         set_req_tile(rt);
         // prime the stream: all of K-tile 0 and the first three parts of K-tile 1 (phase q0 of K-tile 0 then requests A(m1) of 1)
         request(IntTag9<0>{}); request(IntTag9<1>{}); request(IntTag9<2>{}); request(IntTag9<3>{});
-        request(IntTag9<0>{}); request(IntTag9<1>{}); request(IntTag9<2>{});
+        request(IntTag9<0>{}); request(IntTag9<1>{});
+        if constexpr (!PH2) request(IntTag9<2>{});      // two-phase form: L(P0) of K-tile 0 requests B(n1) and A(m1) of K-tile 1
     }
     half_t* const scr = scratch_all + wave * 2048;                          // 4 KiB of epilogue scratch per wave
     float* const bias_lds = reinterpret_cast<float*>(scr);
-    // K-tile 0 of the first tile: A(m0), B(n0) landed for every wave (five younger parts in flight, as in steady state)
+    // K-tile 0 of the first tile: A(m0), B(n0) landed for every wave (the younger parts stay in flight, as in steady state)
     retire();
     CGPT_SLOT_END
 
+#ifdef CGPT_STAMPS
+    unsigned long long st_first = 0, st_loop = 0, st_epi = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
+    bool first_tile = true;
     auto tile_body = [&](auto tnv_tag, int tm, int ncol0) __attribute__((always_inline)) {
         constexpr int TNv = decltype(tnv_tag)::value;                       // column tiles of 16 per wave: 4, or 3 (192-column tile)
         constexpr bool NARROW = TNv == 3;
@@ -168,8 +192,95 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < TNv; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (late) { CGPT_SLOT_END }                                         // the late half enters one slot behind
+        if (late) {                                                         // the late half enters one slot behind
+            // two-phase form, first tile only (later tiles: done at the end of the previous tile's last M(P1)): its share of
+            // B(n1) of the first K-tile must be retired before its partners read that part
+            if constexpr (PH2) { if (first_tile) retire2(IntTag9<6>{}); }
+            CGPT_SLOT_END
+        }
+        first_tile = false;
+#ifdef CGPT_STAMPS
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+        unsigned long long ts_k1 = 0;
+#endif
 
+        if constexpr (PH2) {
+        for (int kt = 0; kt < nk; ++kt, ++c) {
+#ifdef CGPT_STAMPS
+            if (kt == 1) ts_k1 = __builtin_amdgcn_s_memtime();
+#endif
+            const half_t* st = smem9 + (c & 1) * STAGE;
+            // ---------------- P0 = (m0; n0, n1)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf0[j][0] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + k_off0);
+                bf0[j][1] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + k_off1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK + k_off0);
+                af[i][1] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK + k_off1);
+            }
+            CGPT_FENCE
+            request(IntTag9<2>{});                                          // B(n1), A(m1) of K-tile c+1
+            request(IntTag9<3>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            retire2(IntTag9<8>{});                                          // B(n1), A(m1) of this K-tile have landed
+            CGPT_SLOT_END
+#pragma unroll
+            for (int j = 0; j < N1; ++j) {                                  // B(n1) fragments: read under q0's MFMAs
+                bf1[j][0] = *reinterpret_cast<const f16x8*>(st + b_rd + (2 + j) * 16 * BK + k_off0);
+                bf1[j][1] = *reinterpret_cast<const f16x8*>(st + b_rd + (2 + j) * 16 * BK + k_off1);
+            }
+            CGPT_FENCE
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+            CGPT_FENCE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            CGPT_FENCE
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < N1; ++j)
+                        acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[j][ks], af[i][ks], acc[i][2 + j], 0, 0, 0);
+            CGPT_SLOT_END
+            // ---------------- P1 = (m1; n1, n0)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *reinterpret_cast<const f16x8*>(st + a_rd + (4 + i) * 16 * BK + k_off0);
+                af[i][1] = *reinterpret_cast<const f16x8*>(st + a_rd + (4 + i) * 16 * BK + k_off1);
+            }
+            CGPT_FENCE
+            request(IntTag9<0>{});                                          // A(m0), B(n0) of K-tile c+2
+            request(IntTag9<1>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            retire2(IntTag9<8>{});                                          // A(m0), B(n0) of K-tile c+1 have landed
+            CGPT_SLOT_END
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < N1; ++j)
+                        acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[j][ks], af[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], acc[4 + i][j], 0, 0, 0);
+            if (late) retire2(IntTag9<6>{});                                // this wave's share of B(n1) of K-tile c+1 (its partner reads it first)
+            CGPT_SLOT_END
+        }
+        } else {
         for (int kt = 0; kt < nk; ++kt, ++c) {
             const half_t* st = smem9 + (c & 1) * STAGE;
             // ---------------- q0 = (m0, n0)
@@ -246,7 +357,12 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                         acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], acc[4 + i][j], 0, 0, 0);
             CGPT_SLOT_END
         }
+        }   // four-phase form
 
+#ifdef CGPT_STAMPS
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         // the early half waits one slot for its partners' last M: both waves of a SIMD then run their epilogues TOGETHER (one wave
         // alone issues VALU at half the SIMD's rate: with the halves left one slot apart the two epilogues ran one after the other,
         // fc1 + GELU 1 001 -> 1 102 us per launch in the model)
@@ -297,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // reads returned before the next pass overwrites
             }
-            fresh = (t + (int)gridDim.x < ntiles) ? 4 : 0;                  // only a following tile issues the bias request counted above
+            fresh = (!PH2 && t + (int)gridDim.x < ntiles) ? 4 : 0;                  // only a following tile issues the bias request counted above
         } else {
             if constexpr (NARROW) {
                 f32x4 accn[8][3];
@@ -310,6 +426,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                 gemm_epilogue_256<EPI, 8, 4>(p, acc, bias4, tm * BM2 + wr * 128 + e15, ncol0 + wc * 64 + 4 * eg, full);
             }
         }
+#ifdef CGPT_STAMPS
+        st_first += (ts_k1 ? ts_k1 : ts2) - ts0; st_loop += ts2 - ts0; st_epi += __builtin_amdgcn_s_memtime() - ts2;
+#endif
     };
 
     for (; t < ntiles; t += gridDim.x) {
@@ -320,11 +439,17 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         if (narrow) tile_body(IntTag9<3>{}, tm, ncol0);
         else tile_body(IntTag9<4>{}, tm, ncol0);
     }
+#ifdef CGPT_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+        d[0] = __builtin_amdgcn_s_memtime() - st_begin; d[1] = st_first; d[2] = st_loop; d[3] = st_epi;
+    }
+#endif
 #undef CGPT_FENCE
 #undef CGPT_SLOT_END
 }
 
-template <int EPI>
+template <int EPI, bool PH2>
 hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
     constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t) + 32768;   // two stages + epilogue scratch = 160 KiB
     int dev = 0;
@@ -333,7 +458,7 @@ hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
     static bool configured[kMaxDevices9] = {false};
     static int cus[kMaxDevices9] = {0};
     if (!configured[dev]) {
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm9_f16_kernel<EPI>),
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm9_f16_kernel<EPI, PH2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); e != hipSuccess) return e;
         int n = 0;
         if (hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
@@ -342,21 +467,35 @@ hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
     }
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = tiles < cus[dev] ? tiles : cus[dev];                   // one 512-thread workgroup per CU (LDS-limited), persistent
-    hipLaunchKernelGGL((gemm9_f16_kernel<EPI>), dim3(grid), dim3(512), lds_bytes, stream, p);
+    hipLaunchKernelGGL((gemm9_f16_kernel<EPI, PH2>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
+hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream, bool two_phase) {
+    if (two_phase) {
+        switch (epilogue) {
+            case EPI_F16: return launch_v9<EPI_F16, true>(p, stream);
+            case EPI_F16_GELU: return launch_v9<EPI_F16_GELU, true>(p, stream);
+            case EPI_F32: return launch_v9<EPI_F32, true>(p, stream);
+            case EPI_RESID: return launch_v9<EPI_RESID, true>(p, stream);
+            case EPI_PATCH: return launch_v9<EPI_PATCH, true>(p, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
+#ifdef CGPT_LAB   // the four-phase form (v9) is a lab kernel: level with v3 in the K loop, slower at tile boundaries
     switch (epilogue) {
-        case EPI_F16: return launch_v9<EPI_F16>(p, stream);
-        case EPI_F16_GELU: return launch_v9<EPI_F16_GELU>(p, stream);
-        case EPI_F32: return launch_v9<EPI_F32>(p, stream);
-        case EPI_RESID: return launch_v9<EPI_RESID>(p, stream);
-        case EPI_PATCH: return launch_v9<EPI_PATCH>(p, stream);
+        case EPI_F16: return launch_v9<EPI_F16, false>(p, stream);
+        case EPI_F16_GELU: return launch_v9<EPI_F16_GELU, false>(p, stream);
+        case EPI_F32: return launch_v9<EPI_F32, false>(p, stream);
+        case EPI_RESID: return launch_v9<EPI_RESID, false>(p, stream);
+        case EPI_PATCH: return launch_v9<EPI_PATCH, false>(p, stream);
         default: return hipErrorInvalidValue;
     }
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 
 }  // namespace cgpt

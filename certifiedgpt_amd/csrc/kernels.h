@@ -31,15 +31,17 @@ struct GemmParams {
     int ablate = 0;               // measurement only: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
+// gemm9.hip: quadrant phases with a 1.5-K-tile LDS-DMA run-ahead; two_phase = the product form (32 MFMAs per phase), used for
+// long-K shapes; the four-phase form exists in lab builds only
+hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream, bool two_phase);
 #ifdef CGPT_LAB
 hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);   // gemm6.hip: 4-wave 128x128 wave tiles
 hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // gemm8.hip: two 4-wave workgroups per CU, 128x256 tiles
-hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // gemm9.hip: quadrant phases, 1.5-K-tile LDS-DMA run-ahead
 #endif
 extern int g_gemm_ablate;
 extern int g_gemm_group_m;
 extern unsigned long long* g_gemm_dbg;
-extern int g_gemm_kernel;   // kernel override (speed only): 0 auto, 1 = 128x128, 3 = 256x128, 4 = 256x256 phased; lab builds: 2, 5..11
+extern int g_gemm_kernel;   // kernel override (speed only): 0 auto, 1 = 128x128, 3 = 256x128, 4 = 256x256 phased, 14 = 256x256 two-phase quadrant; lab builds: 2, 5..13, 15
 
 // ---------------------------------------------------------------------------------------- attention
 // O[b,q,h*hd + d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d]   (eva_vit.py:133-150,

@@ -17,11 +17,12 @@ DEV = "cuda:0"
 
 def _gemm_kernels():
     """Kernel overrides this build of libcgpt.so accepts (results are identical for every one): the product library has the
-    automatic choice (0), the 128x128 kernel (1), the 256x128 (3) and the 256x256 phased kernel (4); `make LAB=1` adds 2, 5..11."""
+    automatic choice (0), the 128x128 kernel (1), the 256x128 (3), the 256x256 phased (4) and the 256x256 two-phase quadrant kernel (14);
+    `make LAB=1` adds 2, 5..12."""
     L = cg.lib()
     lab = L.cgpt_set_option(b"gemm_kernel", 12) == 0
     L.cgpt_set_option(b"gemm_kernel", 0)
-    return list(range(13)) if lab else [0, 1, 3, 4]
+    return [k for k in range(15) if k != 13] if lab else [0, 1, 3, 4, 14]
 
 
 GEMM_KERNELS = _gemm_kernels()
@@ -275,7 +276,7 @@ def test_fp16_epilogue_value_does_not_depend_on_kernel_or_tile_path(epi):
         outs.append(out)
     assert torch.equal(outs[0], outs[1][:300])
     try:                                                     # ... and every forced kernel on the small launch
-        for kernel in (1, 3, 4):
+        for kernel in (1, 3, 4, 14):
             _lib.check(L.cgpt_set_option(b"gemm_kernel", kernel))
             out = torch.zeros(300, N, device=DEV, dtype=torch.float16)
             _lib.check(L.cgpt_linear_f16(P(Ad), K, P(Wd), K, P(bd), P(out), N, None, N, 300, N, K, epi, stream()))
@@ -288,6 +289,38 @@ def test_fp16_epilogue_value_does_not_depend_on_kernel_or_tile_path(epi):
     _lib.check(L.cgpt_linear_f16(P(Ad), K, P(Wd), K, P(bd), P(out3), N, None, N, 1536, N, K, epi, stream()))
     torch.cuda.synchronize()
     assert torch.equal(outs[1], out3[:1300])
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(25700, 1408, 6144, 0), (5140, 6144, 1408, 1), (2313, 1408, 3072, 3), (1300, 640, 64, 0), (1029, 768, 128, 2)])
+def test_two_phase_quadrant_kernel_is_bit_identical_to_the_phased_kernel(M, N, K, epi):
+    """gemm_kernel 14 (gemm9.hip: quadrant parts requested 1.5 K-tiles ahead behind counted vmcnt waits, the automatic choice for
+    K >= 3072) against gemm_kernel 4 on the same operands, several launches each with competing traffic on a second stream: a
+    fragment read that overtakes its LDS-DMA request shows up as rare wrong tiles, not as a failure of a single clean run."""
+    L = cg.lib()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A = torch.zeros(ru(M, 256), K, device=DEV, dtype=torch.float16); A[:M] = (torch.randn(M, K, device=DEV, generator=g) * 0.5).half()
+    W = torch.zeros(ru(N, 256), K, device=DEV, dtype=torch.float16); W[:N] = (torch.randn(N, K, device=DEV, generator=g) * 0.05).half()
+    b = torch.randn(N, device=DEV, generator=g)
+    aux = torch.randn(M, N, device=DEV, generator=g) if epi == 3 else None
+    dt = torch.float16 if epi < 2 else torch.float32
+    side = torch.cuda.Stream()
+    ja = torch.randn(4096, 4096, device=DEV, dtype=torch.float16)
+
+    def run(kernel):
+        out = torch.full((M, N), 3.0, device=DEV, dtype=dt)
+        _lib.check(L.cgpt_set_option(b"gemm_kernel", kernel))
+        _lib.check(L.cgpt_linear_f16(P(A), K, P(W), K, P(b), P(out), N, P(aux) if aux is not None else None, N, M, N, K, epi, stream()))
+        return out
+    try:
+        ref = run(4)
+        for it in range(8):
+            if it & 1:
+                with torch.cuda.stream(side):
+                    ja @ ja
+            assert torch.equal(run(14), ref), it
+    finally:
+        _lib.check(L.cgpt_set_option(b"gemm_kernel", 0))
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("M,N,K", [(513, 512, 128), (1300, 6144, 1408), (300, 384, 192)])
