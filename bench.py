@@ -22,8 +22,10 @@ WORLD_SIZE differs from --gpus, or a node with fewer than N devices, is an error
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the MLP fc1 GEMM with the GELU epilogue,
 gemm3_f16_kernel<EPI_F16_GELU, 4>): achieved = 2*M*6144*1408 FLOP per launch / its mean launch duration measured with HIP
-events on the launch stream inside the timed region.  `cpu_baseline` times the CPU oracle (oracle/, a port of the
-reference's Smooth + ViT-G forward in fp32 PyTorch) on the host cores, on a bounded sample, on rank 0 at N=1 only.
+events on the launch stream inside the timed region; `roofline.vit_gemms` lists the four ViT GEMM shapes the same way.
+`cpu_baseline` times ONE WHOLE Smooth.certify of BASELINE configs[0] (n0 = n = 10, sigma = 0.25) on the CPU oracle (oracle/, a port
+of the reference's Smooth + ViT-G forward in fp32 PyTorch) on the host cores, on rank 0 at N=1 only, and `parity` compares its
+(label, radius) and per-sample votes with the same call on the GPU.  `single_image_certify_ms` is the reference-shaped call.
 """
 import argparse
 import json
@@ -251,11 +253,11 @@ def main():
     # command under profiles/ is reported when it matches this configuration (batch), else null.
     traffic, traffic_note = None, "no PMC summary for this configuration"
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")) as f:
             pm = json.load(f)["fc1"]
         if world == 1 and headline:
             traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
-            traffic_note = ("bytes per launch from profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+            traffic_note = ("bytes per launch from profiles/r02/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                             "FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted): read %.0f MB + write %.0f MB vs "
                             "algorithmic %.0f MB (A %.0f + W %.0f + out %.0f; full %d-sample batches)" % (
                                 pm["hbm_read_bytes_corrected"] / 1e6, pm["hbm_write_bytes"] / 1e6,

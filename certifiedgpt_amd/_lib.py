@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcgpt.so")
+LIB_PATH = os.environ.get("CGPT_LIB_PATH") or os.path.join(_HERE, "libcgpt.so")   # CGPT_LIB_PATH: another build of the same ABI (A/B measurements)
 
 CGPT_OK = 0
 ERR_NAMES = {1: "CGPT_ERR_INVALID", 2: "CGPT_ERR_NO_DEVICE", 3: "CGPT_ERR_HIP", 4: "CGPT_ERR_NOT_FOUND", 5: "CGPT_ERR_STATE"}

@@ -703,11 +703,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
             int el;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
             const int row_rd = el >> 3, ch_rd = el & 7, r15 = el & 15, g = el >> 4;
+#ifndef CGPT_V3_PASSES
+#define CGPT_V3_PASSES 2
+#endif
+            constexpr int NPS = CGPT_V3_PASSES, RT = 8 / NPS;           // passes, and 16-row tiles per pass (experiment knob; product: 2 x 4)
 #pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
+            for (int ps = 0; ps < NPS; ++ps) {
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int i = ps * 4 + ii;
+                for (int ii = 0; ii < RT; ++ii) {
+                    const int i = ps * RT + ii;
                     const int row = ii * 16 + r15;
 #pragma unroll
                     for (int jj = 0; jj < TNv; ++jj) {
@@ -722,10 +726,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave wrote what it now reads
                 // one 64-bit row address per pass; the 8 stores step by 8 rows (a uniform offset)
-                half_t* dst0 = outp + ((int64_t)etm * BM2 + wr * (BM2 / WM) + ps * 64 + row_rd) * p.ldo + ecol0 + wc * wcols + ch_rd * 8;
+                half_t* dst0 = outp + ((int64_t)etm * BM2 + wr * (BM2 / WM) + ps * (RT * 16) + row_rd) * p.ldo + ecol0 + wc * wcols + ch_rd * 8;
                 const int64_t step = 8 * p.ldo;
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
+                for (int it = 0; it < RT * 2; ++it) {
                     const int row = it * 8 + row_rd;
                     if (!NARROW || ch_rd < 6) {
                         const f16x8 o = *reinterpret_cast<const f16x8*>(scr + row * 64 + ((ch_rd ^ (row & 7)) * 8));
