@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # extra data points (NOT the headline line): BASELINE configs[2] without the Vicuna decode, and the reference's own 448^2 size
-    ap.add_argument("--workload", choices=["vit_head", "encode_img", "rgf"], default="vit_head")
+    ap.add_argument("--workload", choices=["vit_head", "encode_img", "rgf", "minigpt4"], default="vit_head")
     ap.add_argument("--img-size", type=int, default=224)
     ap.add_argument("--n", type=int, default=N)      # BASELINE configs[3]: --n 1000 (sharded 125 / GPU at 8 GPUs)
     ap.add_argument("--n0", type=int, default=N0)
@@ -152,7 +152,8 @@ def main():
     headline = args.workload == "vit_head" and args.img_size == 224 and args.n == N and args.n0 == N0
     n_est, n_sel = args.n, args.n0
     rgf = args.workload == "rgf"                     # BASELINE configs[4]: 8-step RGF x smoothed predict(N) on ViT-G + head
-    mode = "vit_head" if rgf else args.workload
+    gen = args.workload == "minigpt4"                # BASELINE configs[2]: full MiniGPT-4, Vicuna-7B-shaped decode on PyTorch-ROCm
+    mode = "vit_head" if rgf else ("encode_img" if gen else args.workload)
 
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
@@ -201,14 +202,41 @@ def main():
     # Classifier batch capacity.  Smooth.certify_many cuts the (image, sample) rows of a group of images into batches of this
     # size, not aligned to image boundaries, so it is chosen for the GEMMs: 255 samples x 257 tokens = 65 535 rows = 256 tile
     # rows of 256 -> every GEMM's tile count is a multiple of the 256 CUs (200 samples: 201 tile rows, 96 % tile efficiency).
-    per_gpu = 200 if (rgf or args.img_size != 224) else 255
-    group = 1 if rgf else 51                                          # images per certify_many call (51 x 200 = 40 x 255)
+    per_gpu = 200 if (rgf or args.img_size != 224) else (100 if gen else 255)
+    group = 1 if (rgf or gen) else 51                                 # images per certify_many call (51 x 200 = 40 x 255)
     if os.environ.get("CGPT_BENCH_BATCH"):                            # measurement only: "capacity,group"
         per_gpu, group = (int(v) for v in os.environ["CGPT_BENCH_BATCH"].split(","))
     clf = cg.HipClassifier(mode=mode, num_classes=NUM_CLASSES, max_batch=per_gpu, device=local, img_size=args.img_size)
     clf.init_synthetic(seed=0)                                         # identical weights on every rank
-    smooth = cg.Smooth(clf, NUM_CLASSES, SIGMA, seed=42)
     images = synthetic_images(args.steps + args.warmup, dev, args.img_size)
+    base = clf
+    if gen:
+        # BASELINE configs[2]: encode_img in HIP + a frozen decoder of the Vicuna-7B ARCHITECTURE (LlamaConfig 4096 / 32 layers / 32
+        # heads / 11008 / vocab 32000, fp16) with random-init weights -- the checkpoint is not in the container and nothing is ever
+        # downloaded -- greedy decode of 20 new tokens per noisy copy (the reference's max_new_tokens), HF `generate` on PyTorch-ROCm.
+        # Tokenizer: the word-hash stand-in; classes: the answers of a first 100-sample batch (frozen), everything else "other".
+        from transformers import LlamaConfig, LlamaForCausalLM
+        from certifiedgpt_amd.minigpt4 import MiniGPT4Classifier, WordHashTokenizer, prepare_texts
+        from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
+        lcfg = LlamaConfig(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                           num_key_value_heads=32, max_position_embeddings=2048, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+        torch.manual_seed(0)
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float16)
+        try:
+            with torch.device(dev):
+                llm = LlamaForCausalLM(lcfg).eval()
+        finally:
+            torch.set_default_dtype(prev)
+        for prm in llm.parameters():
+            prm.requires_grad = False
+        tok = WordHashTokenizer(32000)
+        prompt = prepare_texts(["<Img><ImageHere></Img> [vqa] what is shown in the picture"])[0]
+        probe = MiniGPT4Classifier(clf, llm, tok, prompt, AnswerLabelMap(NUM_CLASSES), max_new_tokens=20, max_batch=per_gpu)
+        emb = clf.encode_img_noisy(images[0], 0, per_gpu, SIGMA, 42)
+        vocab = sorted(set(probe.generate_from_embeds(emb, prompt)))[:NUM_CLASSES - 1]
+        base = MiniGPT4Classifier(clf, llm, tok, prompt, AnswerLabelMap(NUM_CLASSES, vocab, frozen=True), max_new_tokens=20, max_batch=per_gpu)
+    smooth = cg.Smooth(base, NUM_CLASSES, SIGMA, seed=42, non_certifiable=(base.label_map.other_id,) if gen else ())
     torch.cuda.synchronize()
 
     def barrier():
@@ -327,6 +355,10 @@ def main():
             T = (args.img_size // 14) ** 2 + 1
             what = (f"8-step RGF attack (1 direction per step) + smoothed predict, {attack.forwards_per_image(n_est)} forwards per image"
                     if rgf else f"Smooth.certify n0={n_sel} n={n_est} alpha=0.001 sigma=0.5")
+            if gen:
+                what += (" over full MiniGPT-4: encode_img in HIP + random-init decoder of the Vicuna-7B architecture (fp16, HF generate on "
+                         "PyTorch-ROCm, 20 new tokens per noisy copy, batches of %d), answers -> classes by a frozen vocabulary of %d answers "
+                         "(BASELINE configs[2])" % (per_gpu, len(base.label_map.answers)))
             line["config"]["workload"] = (f"NON-HEADLINE data point: mode={mode}, image {args.img_size}x{args.img_size} (T={T}), "
                                           f"random-init weights, {what}")
             line["config"].update({"n0": n_sel, "n": n_est})

@@ -39,6 +39,52 @@ def clean_answer(text: str) -> str:
     return text.split(r"[/INST]")[-1].strip()
 
 
+class WordHashTokenizer:
+    """Stand-in for LlamaTokenizer where no tokenizer model file exists (the container has no Vicuna directory and nothing is
+    ever downloaded): words map to ids by a stable hash into [3, vocab_size), id k decodes to the word "w<k>" (token-id strings
+    as answers).  It offers exactly the tokenizer surface `MiniGPTBase` uses: `__call__(text, return_tensors="pt",
+    add_special_tokens=...)` -> object with `.input_ids` / `.to(device)`, and `decode(ids, skip_special_tokens=True)`.
+    Used by the tests and by `bench.py --workload minigpt4` (synthetic decoder of the Vicuna-7B architecture)."""
+    pad_token_id, bos_token_id, eos_token_id = 0, 1, 2
+
+    class _Encoding:
+        def __init__(self, ids):
+            self.input_ids = ids
+            self.attention_mask = torch.ones_like(ids)
+
+        def to(self, device):
+            self.input_ids = self.input_ids.to(device)
+            self.attention_mask = self.attention_mask.to(device)
+            return self
+
+    def __init__(self, vocab_size=96):
+        self.vocab_size = int(vocab_size)
+
+    def _word_id(self, w):
+        h = 0
+        for ch in w:
+            h = (h * 131 + ord(ch)) % 1000003
+        return 3 + h % (self.vocab_size - 3)
+
+    def __call__(self, text, return_tensors="pt", add_special_tokens=True, **_):
+        ids = [self._word_id(w) for w in text.split()]
+        if add_special_tokens:
+            ids = [self.bos_token_id] + ids
+        return self._Encoding(torch.tensor([ids], dtype=torch.long))
+
+    def decode(self, ids, skip_special_tokens=True):
+        out = []
+        for t in ids.tolist():
+            if t in (self.pad_token_id, self.bos_token_id):
+                if not skip_special_tokens:
+                    out.append("<s>" if t == self.bos_token_id else "<pad>")
+            elif t == self.eos_token_id:
+                out.append("</s>")                       # the reference splits on the literal stop sign, minigpt_base.py:445
+            else:
+                out.append(f"w{t}")
+        return " ".join(out)
+
+
 class MiniGPT4Classifier:
     """:param encoder: a `HipClassifier(mode="encode_img")` (or any object with `encode_img(images) -> (emb, atts)` and
                `encode_img_noisy(x, first_sample, num, sigma, seed) -> emb`, emb = [B, queries, llm_hidden])

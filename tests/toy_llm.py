@@ -7,45 +7,12 @@ VOCAB = 96
 PAD, BOS, EOS = 0, 1, 2
 
 
-class _Encoding:
-    def __init__(self, ids):
-        self.input_ids = ids
-        self.attention_mask = torch.ones_like(ids)
-
-    def to(self, device):
-        self.input_ids = self.input_ids.to(device)
-        self.attention_mask = self.attention_mask.to(device)
-        return self
+from certifiedgpt_amd.minigpt4 import WordHashTokenizer
 
 
-class ToyTokenizer:
-    """Words -> ids by a stable hash into [3, VOCAB); id k decodes to the word f"w{k}" (token-id strings as answers)."""
-    pad_token_id, bos_token_id, eos_token_id = PAD, BOS, EOS
-
-    @staticmethod
-    def _word_id(w):
-        h = 0
-        for ch in w:
-            h = (h * 131 + ord(ch)) % 1000003
-        return 3 + h % (VOCAB - 3)
-
-    def __call__(self, text, return_tensors="pt", add_special_tokens=True, **_):
-        ids = [self._word_id(w) for w in text.split()]
-        if add_special_tokens:
-            ids = [BOS] + ids
-        return _Encoding(torch.tensor([ids], dtype=torch.long))
-
-    def decode(self, ids, skip_special_tokens=True):
-        out = []
-        for t in ids.tolist():
-            if t in (PAD, BOS):
-                if not skip_special_tokens:
-                    out.append("<s>" if t == BOS else "<pad>")
-            elif t == EOS:
-                out.append("</s>")                       # the reference splits on the literal stop sign, minigpt_base.py:445
-            else:
-                out.append(f"w{t}")
-        return " ".join(out)
+class ToyTokenizer(WordHashTokenizer):
+    def __init__(self):
+        super().__init__(VOCAB)
 
 
 def tiny_llama(hidden=64, seed=0, dtype=torch.float32, device="cpu"):
