@@ -241,7 +241,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])      # this rank's own GPU, explicitly
+            else:
+                dist.barrier()
 
     attack = cg.RGFAttack(smooth, steps=8, num_dirs=1, delta=0.5, lr=0.05, eps=0.25, dir_seed=1234) if rgf else None
 
