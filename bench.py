@@ -21,7 +21,7 @@ reference's launcher starts one process per device, launch.py:110-120), relays i
 WORLD_SIZE differs from --gpus, or a node with fewer than N devices, is an error (exit code 2), never a silent 1-GPU measurement.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the MLP fc1 GEMM with the GELU epilogue,
-gemm3_f16_kernel<EPI_F16_GELU, 4>): achieved = 2*M*6144*1408 FLOP per launch / its mean launch duration measured with HIP
+gemm9_f16_kernel<EPI_F16_GELU, true>, the two-phase quadrant kernel): achieved = 2*M*6144*1408 FLOP per launch / its mean launch duration measured with HIP
 events on the launch stream inside the timed region; `roofline.vit_gemms` lists the four ViT GEMM shapes the same way.
 `cpu_baseline` times ONE WHOLE Smooth.certify of BASELINE configs[0] (n0 = n = 10, sigma = 0.25) on the CPU oracle (oracle/, a port
 of the reference's Smooth + ViT-G forward in fp32 PyTorch) on the host cores, on rank 0 at N=1 only, and `parity` compares its
@@ -341,7 +341,7 @@ def main():
                                        f"batches, one int64[G,2,{NUM_CLASSES}] all-reduce per call)")},
             "forwards_per_s": value * (N0 + N),
             "vit_tflops_end_to_end": value * (N0 + N) * F_VIT / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm3_f16_kernel<EPI_F16_GELU, 4> (ViT MLP fc1 + GELU, M=batch*257, N=6144, K=1408)",
+            "roofline": {"bound": "mfma", "kernel": "gemm9_f16_kernel<EPI_F16_GELU, two-phase> (ViT MLP fc1 + GELU, M=batch*257, N=6144, K=1408)",
                          "achieved": fc1_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": fc1_tflops / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "launches": fc1_n, "avg_launch_ms": fc1_ms / max(fc1_n, 1),

@@ -1199,10 +1199,9 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
         if (force == 13) return launch_v9_epi(epilogue, p, stream, false);   // lab: v9 wherever the automatic choice is v3
         if (force == 15) return launch_v9_epi(epilogue, p, stream, true);    // lab: the two-phase quadrant kernel likewise
 #endif
-        // long K (ViT MLP fc2: K = 6144, 96 K-tiles per output tile): the two-phase quadrant kernel (gemm9.hip) -- its K loop is
-        // ~5 % faster in the model (fc2 905 -> 861 us per launch), its tile boundaries slower (fc1, 22 K-tiles per tile: 986 -> 1 017)
-        if (p.K >= 3072) return launch_v9_epi(epilogue, p, stream, true);
-        return launch_v3_epi<4>(epilogue, p, stream);
+        // the two-phase quadrant kernel (gemm9.hip) wins on every ViT shape in the model: qkv 650 -> 611, proj 238 -> 229,
+        // fc1 + GELU ~1 000 -> 976, fc2 859 -> 823 us per 255-sample launch (profiles/r02/gemm_two_phase_variants.txt)
+        return launch_v9_epi(epilogue, p, stream, true);
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

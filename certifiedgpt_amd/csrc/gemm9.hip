@@ -1,4 +1,6 @@
 // gemm9.hip -- 256 x 256 x 64 fp16 MFMA GEMM, quadrant-phased with a 1.5-K-tile LDS-DMA run-ahead.
+// The product kernel is its TWO-PHASE form (template parameter PH2, described at the kernel); the four-phase form described
+// first is the lab experiment it grew out of.
 //
 // Same tile, LDS image, swizzle, transposed accumulators, persistent XCD-aware tile walk, 192-column last tiles and epilogues as
 // gemm3_f16_kernel (gemm.hip), different K loop.  What v3 loses (in-kernel stamps, profiles/r01/gemm_variants.txt: 2 510-2 580
@@ -38,17 +40,21 @@ namespace {
 constexpr int kMaxDevices9 = 64;
 template <int V> struct IntTag9 { static constexpr int value = V; };
 
-// PH2 = true ("v10"): TWO phases per K-tile instead of four -- P0 = quadrants q0 + q1 (32 MFMAs), P1 = q2 + q3 -- i.e. half the
-// barriers and L segments that fit the partner's 512-cycle M segment.  Model behind it (it reproduces the stamped cycle counts of
-// v3 with and without loads, of v3's two-phase form without loads and of v9: a fragment read costs ~16 cycles of a CU's LDS
-// pipe with four waves reading, + ~170 cycles of latency per L segment, an LDS-DMA request ~25, a barrier ~25): with 16-MFMA
-// phases (256 cycles) every L segment that holds 8 or 12 reads overruns its slot; with 32-MFMA phases L(P0) = 12 reads + 4
-// requests and L(P1) = 8 reads + 4 requests both fit.  v3's own two-phase form loses because all eight requests of a K-tile
-// fall into one L segment and the second half of a K-tile has no time to land; here the parts are requested as in v9:
-//     L(P1) of K-tile c:   A(m0), B(n0) of K-tile c+2          L(P0) of K-tile c+1:   B(n1), A(m1) of K-tile c+2
-// B(n1)'s four fragment reads are issued at the START of M(P0) (they complete under q0's 16 MFMAs), which keeps L(P0) at 12 reads.
-// Waits: end of L(P0) and of L(P1): vmcnt(8) (four younger parts stay in flight); the late half, whose partner reads B(n1) one
-// slot earlier than it does itself, also retires its share of the next K-tile's B(n1) at the end of M(P1): vmcnt(6).
+// PH2 = true: TWO phases per K-tile instead of four -- P0 = quadrants q0 + q1 (32 MFMAs), P1 = q2 + q3 -- i.e. half the barriers,
+// and L segments that fit the partner's 512-cycle M segment.  With 16-MFMA phases (256 cycles) every L segment that holds 8 or 12
+// fragment reads overruns its slot whatever the request placement (v3 and the four-phase form here run the same ~2 550 cycles per
+// K-tile); v3's own two-phase form loses because all eight requests of a K-tile fall into one L segment and the second half of a
+// K-tile gets no time to land.  Here:
+//     L(P0): reads A(m0) [8], B(n0) [4], B(n1) [4];  requests A(m1) of K-tile c+1                 (16 reads + 2 requests)
+//     M(P0): 32 MFMAs, nothing else (B(n1)'s reads under q0's MFMAs -- a wait in the middle of the cluster -- cost 3.6 % on fc2)
+//     L(P1): reads A(m1) [8];  requests A(m0), B(n0), B(n1) of K-tile c+2 (all three last read in L(P0))   (8 reads + 6 requests)
+//     M(P1): 32 MFMAs
+// Every part is requested 6 slots = 1.5 K-tiles before its first read; both L segments end with vmcnt(8) (the four younger parts
+// stay in flight), lgkmcnt(0) and the barrier, so a part is retired by EVERY wave at least one barrier before any wave reads it,
+// and re-requested at least one barrier after every wave's reads of it have returned.  In the model (us per 255-sample launch,
+// v3 | this): qkv 650 | 611, proj 238.5 | 228.7, fc1 + GELU 995-1018 | 976, fc2 859 | 823 (profiles/r02/gemm_two_phase_variants.txt,
+// which also holds what did not help: s_setprio around the MFMA clusters +0.6 %, static priority for the late half -2 % alone but
+// +0.7 % on top of this form, store-tolerant counted waits after an epilogue 0 %).
 template <int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     constexpr int BM2 = 256, BN_ = 256;
@@ -130,11 +136,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     // four waits after such an epilogue they are younger than the part waited for, so the count grows by them and the stores
     // stay in flight (any other epilogue: the plain count, which then also waits for its stores -- correct, slower).
     int fresh = 0;
-    auto retire2 = [&](auto n_tag) __attribute__((always_inline)) {          // two-phase form: plain counts
-        constexpr int NP = decltype(n_tag)::value;
+    auto retire2 = [&](auto) __attribute__((always_inline)) {               // two-phase form: the four younger parts stay in flight
         if (!req_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
     auto retire = [&]() __attribute__((always_inline)) {
         if constexpr (PH2) { retire2(IntTag9<8>{}); return; }
@@ -163,8 +167,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         set_req_tile(rt);
         // prime the stream: all of K-tile 0 and the first three parts of K-tile 1 (phase q0 of K-tile 0 then requests A(m1) of 1)
         request(IntTag9<0>{}); request(IntTag9<1>{}); request(IntTag9<2>{}); request(IntTag9<3>{});
-        request(IntTag9<0>{}); request(IntTag9<1>{});
-        if constexpr (!PH2) request(IntTag9<2>{});      // two-phase form: L(P0) of K-tile 0 requests B(n1) and A(m1) of K-tile 1
+        request(IntTag9<0>{}); request(IntTag9<1>{}); request(IntTag9<2>{});
     }
     half_t* const scr = scratch_all + wave * 2048;                          // 4 KiB of epilogue scratch per wave
     float* const bias_lds = reinterpret_cast<float*>(scr);
@@ -175,8 +178,17 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #ifdef CGPT_STAMPS
     unsigned long long st_first = 0, st_loop = 0, st_epi = 0;
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+    // phase stamps of the two-phase K loop (cycles summed over all K-tiles): 0 L(P0) body incl. its waits, 1 barrier, 2 M(P0),
+    // 3 barrier, 4 L(P1), 5 barrier, 6 M(P1), 7 barrier.  The MFMA-only segments end with an s_nop-free stamp: an s_memtime is issued
+    // in order, so it is taken when the last MFMA has ISSUED, not completed.
+    unsigned long long ph9[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph_last = 0;
+#define CGPT9_PH_BEGIN ph_last = __builtin_amdgcn_s_memtime();
+#define CGPT9_PH(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph9[k] += tn_ - ph_last; ph_last = tn_; }
+#else
+#define CGPT9_PH_BEGIN
+#define CGPT9_PH(k)
 #endif
-    bool first_tile = true;
     auto tile_body = [&](auto tnv_tag, int tm, int ncol0) __attribute__((always_inline)) {
         constexpr int TNv = decltype(tnv_tag)::value;                       // column tiles of 16 per wave: 4, or 3 (192-column tile)
         constexpr bool NARROW = TNv == 3;
@@ -192,13 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < TNv; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (late) {                                                         // the late half enters one slot behind
-            // two-phase form, first tile only (later tiles: done at the end of the previous tile's last M(P1)): its share of
-            // B(n1) of the first K-tile must be retired before its partners read that part
-            if constexpr (PH2) { if (first_tile) retire2(IntTag9<6>{}); }
-            CGPT_SLOT_END
-        }
-        first_tile = false;
+        if (late) { CGPT_SLOT_END }                                         // the late half enters one slot behind
 #ifdef CGPT_STAMPS
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
         unsigned long long ts_k1 = 0;
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             if (kt == 1) ts_k1 = __builtin_amdgcn_s_memtime();
 #endif
             const half_t* st = smem9 + (c & 1) * STAGE;
+            CGPT9_PH_BEGIN
             // ---------------- P0 = (m0; n0, n1)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -221,17 +228,18 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                 af[i][0] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK + k_off0);
                 af[i][1] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK + k_off1);
             }
-            CGPT_FENCE
-            request(IntTag9<2>{});                                          // B(n1), A(m1) of K-tile c+1
-            request(IntTag9<3>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            retire2(IntTag9<8>{});                                          // B(n1), A(m1) of this K-tile have landed
-            CGPT_SLOT_END
 #pragma unroll
-            for (int j = 0; j < N1; ++j) {                                  // B(n1) fragments: read under q0's MFMAs
+            for (int j = 0; j < N1; ++j) {
                 bf1[j][0] = *reinterpret_cast<const f16x8*>(st + b_rd + (2 + j) * 16 * BK + k_off0);
                 bf1[j][1] = *reinterpret_cast<const f16x8*>(st + b_rd + (2 + j) * 16 * BK + k_off1);
             }
+            CGPT_FENCE
+            request(IntTag9<3>{});                                          // A(m1) of K-tile c+1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            retire2(IntTag9<8>{});                                          // A(m1) of this K-tile has landed (read in L(P1))
+            CGPT9_PH(0)
+            CGPT_SLOT_END
+            CGPT9_PH(1)
             CGPT_FENCE
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -240,9 +248,6 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
-            CGPT_FENCE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            CGPT_FENCE
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -250,7 +255,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < N1; ++j)
                         acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[j][ks], af[i][ks], acc[i][2 + j], 0, 0, 0);
+            CGPT9_PH(2)
             CGPT_SLOT_END
+            CGPT9_PH(3)
             // ---------------- P1 = (m1; n1, n0)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -258,11 +265,14 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                 af[i][1] = *reinterpret_cast<const f16x8*>(st + a_rd + (4 + i) * 16 * BK + k_off1);
             }
             CGPT_FENCE
-            request(IntTag9<0>{});                                          // A(m0), B(n0) of K-tile c+2
+            request(IntTag9<0>{});                                          // A(m0), B(n0), B(n1) of K-tile c+2: all last read in L(P0)
             request(IntTag9<1>{});
+            request(IntTag9<2>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            retire2(IntTag9<8>{});                                          // A(m0), B(n0) of K-tile c+1 have landed
+            retire2(IntTag9<8>{});                                          // A(m0), B(n0), B(n1) of K-tile c+1 have landed
+            CGPT9_PH(4)
             CGPT_SLOT_END
+            CGPT9_PH(5)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -277,8 +287,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], acc[4 + i][j], 0, 0, 0);
-            if (late) retire2(IntTag9<6>{});                                // this wave's share of B(n1) of K-tile c+1 (its partner reads it first)
+            CGPT9_PH(6)
             CGPT_SLOT_END
+            CGPT9_PH(7)
         }
         } else {
         for (int kt = 0; kt < nk; ++kt, ++c) {
@@ -443,6 +454,8 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     if (p.dbg && lane == 0) {
         unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
         d[0] = __builtin_amdgcn_s_memtime() - st_begin; d[1] = st_first; d[2] = st_loop; d[3] = st_epi;
+        unsigned long long* e = p.dbg + (size_t)gridDim.x * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8;   // second table: phase stamps
+        for (int k = 0; k < 8; ++k) e[k] = ph9[k];
     }
 #endif
 #undef CGPT_FENCE

@@ -211,8 +211,8 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
 
 /* Process-wide SPEED knobs.  No option changes a result: every accepted value gives bit-identical outputs (tested).
  *   "gemm_kernel": 0 = automatic choice (default); 1 = 128x128 register-staged tile, 3 = 256x128 direct-to-LDS tile,
- *                  4 = 256x256 phase-alternating tile (the automatic choice for M >= 1024), 14 = 256x256 two-phase quadrant tile
- *                  with a 1.5-K-tile LDS-DMA run-ahead (the automatic choice for M >= 1024 and K >= 3072).
+ *                  4 = 256x256 phase-alternating tile, 14 = 256x256 two-phase quadrant tile with a 1.5-K-tile LDS-DMA run-ahead (the
+ *                  automatic choice for M >= 1024 when the shape has more than 128 tiles of 256x256).
  *   "gemm_ablate": bit mask; each bit turns ONE optimisation of the 256x256 kernel off without changing results:
  *                  16 = early request of the next tile's first K-tile, 512 = LDS-transposed fp16 epilogue, 1024 = counted
  *                  wait at tile start, 8192 = register-exchange instead of LDS-transposed GELU epilogue, 16384 = 192-column

@@ -7,8 +7,7 @@ import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "pmc_summary")
 GROUPS = [["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"], ["TCC_HIT_sum", "TCC_MISS_sum"]]
-KERNELS = {"layernorm": "layernorm4_", "gemm_f16out": "gemm3_f16_kernel<0, 4>", "attention": "attention_kernel<88", "fc1": "gemm3_f16_kernel<1, 4>",
-           "fc2_two_phase": "gemm9_f16_kernel<0, true>"}
+KERNELS = {"layernorm": "layernorm4_", "gemm_f16out": "gemm9_f16_kernel<0, true>", "attention": "attention_kernel<88", "fc1": "gemm9_f16_kernel<1, true>"}
 
 
 def main():
