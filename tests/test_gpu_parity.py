@@ -430,3 +430,35 @@ def test_certify_many_is_bit_identical_to_consecutive_certify_calls():
         pair = clf.sample_counts_pair(xs[i], 7 + 11 * i, 3, 100 + 11 * i, 4, 16, 0.25, 5)
         assert torch.equal(tab[i], pair), i
     assert int(tab.sum()) == 5 * 7
+
+
+def test_sample_counts_can_be_captured_in_a_hip_graph():
+    """Nothing is allocated, freed or synchronised inside cgpt_sample_counts* and every launch goes to the caller's stream
+    (include/cgpt.h), so a caller may capture a whole `_sample_noise` into a hipGraph (here through torch.cuda.CUDAGraph) and
+    replay it: the replay re-draws the SAME sample indices on whatever image the captured buffer then holds."""
+    K = 10
+    clf, p16, params, cfg = tiny_pair(mo.MODE_ENCODE_IMG, num_classes=K, max_batch=16)
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    x_static = x0.clone()
+    want = clf.sample_counts(x_static, 3, 40, 16, 0.25, 5).clone()       # eager (also warms every per-device launch cache)
+    torch.cuda.synchronize()
+    counts = torch.zeros(K, dtype=torch.int64, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            clf.sample_counts(x_static, 3, 40, 16, 0.25, 5, counts=counts)
+    torch.cuda.current_stream().wait_stream(side)
+    counts.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(counts, want)
+    g.replay()                                                            # votes are ADDED into the histogram
+    torch.cuda.synchronize()
+    assert torch.equal(counts, 2 * want)
+    x_static.copy_(x0 * 0.5 + 0.1)                                        # another image in the captured buffer
+    counts.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(counts, clf.sample_counts(x_static, 3, 40, 16, 0.25, 5))
