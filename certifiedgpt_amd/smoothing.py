@@ -54,7 +54,8 @@ class Smooth(object):
         :param seed: key of the counter-based noise stream; sample indices never repeat within one Smooth object
         :param device_stats: finish certify / predict on the GPU (cgpt_certify_device / cgpt_predict_device: wavefront
                arg-max, Clopper-Pearson bound, binomial test, Phi^-1 in float64) and copy back 16 bytes instead of the
-               histograms; same float64 code as the host path
+               histograms; same float64 code as the host path.  Applies to `certify` and `predict`; `certify_many` finishes its
+               G images' statistics on the host (one copy of the [G,2,K] table)
         :param non_certifiable: class ids that are not classes of the certificate (the "other" bucket of an answer
                vocabulary, agents/label_adapter.py): certify / predict return ABSTAIN when such a class comes out on top
         """
