@@ -1,4 +1,4 @@
-"""Text -> label adapter ("decoder-to-label" mapping, reference README.md:28-29; there is NO code for it in the reference).
+r"""Text -> label adapter ("decoder-to-label" mapping, reference README.md:28-29; there is NO code for it in the reference).
 
 A generated answer string is normalised and looked up in an answer vocabulary of at most `num_classes - 1` entries; the last
 class id is "other".  The normaliser reproduces the VQA accuracy normaliser the reference ships for scoring
@@ -49,17 +49,41 @@ def _build_contractions():
 _CONTRACTIONS = _build_contractions()
 
 
-def normalize_answer(text: str) -> str:
-    t = text.replace("\n", " ").replace("\t", " ").strip()
+def _process_punctuation(t: str) -> str:
+    """vqa_eval.py:249-259."""
     out = t
     for p in _PUNCT:
         if (p + " " in t or " " + p in t) or _COMMA_NUM.search(t) is not None:
             out = out.replace(p, "")
         else:
             out = out.replace(p, " ")
-    out = _PERIOD.sub("", out)
+    return _PERIOD.sub("", out)
+
+
+def normalize_answer(text: str) -> str:
+    """The clean-up the reference applies to a PREDICTED answer before scoring (vqa_eval.py:211-216 + :249-274)."""
+    out = _process_punctuation(text.replace("\n", " ").replace("\t", " ").strip())
     words = [_NUMBERS.get(w, w) for w in out.lower().split()]
     return " ".join(_CONTRACTIONS.get(w, w) for w in words if w not in _ARTICLES)
+
+
+def vqa_accuracy(answer: str, gt_answers) -> float:
+    """VQA accuracy of one predicted answer against the (ten) human answers of a question, as the reference's evaluation loop
+    computes it (vqa_eval.py:211-247, the scoring behind agents/minigpt4_eval_agent.py:108-113): the prediction is normalised;
+    the ground-truth answers only have their punctuation processed, and only when they are not all identical; for each ground-truth
+    answer the prediction scores min(1, matches among the OTHER answers / 3), averaged over the answers.  Pinned by goldens emitted
+    by the reference's own VQAEval.evaluate (tests/golden/label_adapter_golden.json, `vqa_accuracy`)."""
+    res = normalize_answer(answer)
+    gts = list(gt_answers)
+    if not gts:
+        return 0.0
+    if len(set(gts)) > 1:
+        gts = [_process_punctuation(g) for g in gts]
+    total = 0.0
+    for i in range(len(gts)):
+        matches = sum(1 for j, g in enumerate(gts) if j != i and g == res)
+        total += min(1.0, matches / 3.0)
+    return total / len(gts)
 
 
 class AnswerLabelMap:

@@ -47,6 +47,18 @@ class CertifyLoop:
         if f:
             print(header, file=f, flush=True)
         def emit(idx, label, pred, radius, dt):
+            if isinstance(label, (list, tuple)):
+                # a VQA sample: `label` is the list of human answers; the prediction is the answer text of the certified class
+                # ("" when abstaining) and `correct` its VQA accuracy in [0, 1] (vqa_eval.py:211-247; label_adapter.vqa_accuracy)
+                from .label_adapter import vqa_accuracy
+                answers = getattr(getattr(smooth.base_classifier, "label_map", None), "answers", [])
+                text = answers[int(pred)] if 0 <= int(pred) < len(answers) else ""
+                rec = dict(idx=idx, label=-1, predict=int(pred), radius=float(radius), correct=vqa_accuracy(text, label), time=dt,
+                           answer=text)
+                self.records.append(rec)
+                if f:
+                    print(f"{idx}\t{'|'.join(sorted(set(label)))}\t{text or 'ABSTAIN'}\t{radius:.6f}\t{rec['correct']:.3f}\t{dt:.3f}", file=f, flush=True)
+                return
             rec = dict(idx=idx, label=int(label), predict=int(pred), radius=float(radius), correct=int(pred == label), time=dt)
             self.records.append(rec)
             if f:
@@ -94,7 +106,7 @@ class CertifyLoop:
                "accuracy": sum(r["correct"] for r in self.records) / n,
                "images_per_s": len(self.records) / max(sum(r["time"] for r in self.records), 1e-9)}
         for r0 in radii:   # certified accuracy at radius r: correct and certified radius >= r (README.md:52-59)
-            out[f"certified_acc@{r0}"] = sum(r["correct"] and r["radius"] >= r0 for r in self.records) / n
+            out[f"certified_acc@{r0}"] = sum(r["correct"] * (r["radius"] >= r0) for r in self.records) / n
         return out
 
 

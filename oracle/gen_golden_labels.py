@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Golden vectors for the text->label normaliser: outputs of the REFERENCE's own VQA answer normaliser
 (common/vqa_tools/vqa_eval.py: the clean-up at :211-216, processPunctuation :249-259, processDigitArticle :261-274) on a list
-of answer strings, among them every key of its contraction table (as a lone word and inside a sentence) and the contracted
-forms themselves.  Build container only; only the JSON travels.
+of answer strings (`cases`), among them every key of its contraction table (as a lone word and inside a sentence) and the contracted
+forms themselves; and (`vqa_accuracy`) the VQA accuracy of a predicted answer against ten ground-truth answers as the
+reference's own VQAEval.evaluate computes it (vqa_eval.py:196-247).  Build container only; only the JSON travels.
 
     python oracle/gen_golden_labels.py
 """
@@ -33,6 +34,41 @@ for a in ANSWERS:
     r = ev.processPunctuation(r)
     r = ev.processDigitArticle(r)
     out.append({"answer": a, "normalized": r})
+# ---- VQA accuracy of one predicted answer against ten ground-truth answers: the reference's own VQAEval.evaluate (vqa_eval.py:196-247)
+# run on stand-in VQA objects that expose exactly what it touches (getQuesIds, .qa); one question per case.
+class _VQA:
+    def __init__(self, qa):
+        self.qa = qa
+
+    def getQuesIds(self):
+        return list(self.qa.keys())
+
+
+def ref_accuracy(answer, gts):
+    import io, contextlib
+    gt = {1: {"answers": [{"answer": a, "answer_confidence": "yes", "answer_id": i + 1} for i, a in enumerate(gts)],
+              "question_type": "what", "answer_type": "other", "image_id": 1, "question_id": 1}}
+    res = {1: {"answer": answer, "question_id": 1}}
+    e = mod.VQAEval(_VQA(gt), _VQA(res), n=6)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e.evaluate()
+    return e.evalQA[1] / 100.0
+
+
+ACC_CASES = [
+    ("yes", ["yes"] * 10), ("Yes.", ["yes"] * 10), ("no", ["yes"] * 10), ("yes", ["yes"] * 3 + ["no"] * 7), ("yes", ["yes"] * 2 + ["no"] * 8),
+    ("yes", ["yes"] * 1 + ["no"] * 9), ("no", ["yes"] * 3 + ["no"] * 7), ("two", ["2"] * 6 + ["two"] * 4), ("2", ["2"] * 6 + ["two"] * 4),
+    ("a dog", ["dog"] * 5 + ["a dog"] * 5), ("dog", ["dog"] * 5 + ["a dog"] * 5), ("the dog", ["dog"] * 10),
+    ("dont know", ["don't know"] * 4 + ["unknown"] * 6), ("don't know", ["don't know"] * 4 + ["unknown"] * 6),
+    ("red, white", ["red white"] * 4 + ["red, white"] * 3 + ["white"] * 3), ("skate-board", ["skateboard"] * 5 + ["skate board"] * 5),
+    ("frisbee?", ["frisbee"] * 9 + ["disc"]), ("3.5", ["3.5"] * 2 + ["4"] * 8), ("1,000", ["1000"] * 4 + ["1,000"] * 6),
+    ("blue", ["blue", "blue", "blue", "navy", "navy", "dark blue", "dark blue", "teal", "aqua", "blue"]),
+    ("navy", ["blue", "blue", "blue", "navy", "navy", "dark blue", "dark blue", "teal", "aqua", "blue"]),
+    ("", ["yes"] * 10), ("ten people", ["10 people"] * 3 + ["ten people"] * 3 + ["many"] * 4), ("U.S.A.", ["usa"] * 5 + ["u.s.a."] * 5),
+    ("w17 w5", ["w17 w5"] * 4 + ["w3"] * 6), ("maam", ["ma'am"] * 10),
+]
+acc = [{"answer": a, "gt_answers": g, "accuracy": ref_accuracy(a, g)} for a, g in ACC_CASES]
+
 path = os.path.join(ROOT, "tests", "golden", "label_adapter_golden.json")
-json.dump({"generator": "oracle/gen_golden_labels.py", "cases": out}, open(path, "w"), indent=0)
-print("wrote", path, len(out))
+json.dump({"generator": "oracle/gen_golden_labels.py", "cases": out, "vqa_accuracy": acc}, open(path, "w"), indent=0)
+print("wrote", path, len(out), len(acc))

@@ -128,3 +128,34 @@ def test_smooth_abstains_on_non_certifiable_top_class():
     assert lab == 2 and abs(rad - 0.3782577025559939) < 1e-9
     p = t.predict(torch.zeros(3, 8, 8), 100, 0.001, 50)
     assert p == 2 and isinstance(p, np.int64)                 # smoothing.py:79 returns an int64 ndarray element
+
+
+def test_vqa_accuracy_matches_the_references_evaluation_loop():
+    import os
+    from conftest import GOLDEN
+    from certifiedgpt_amd.agents.label_adapter import vqa_accuracy
+    cases = json.load(open(os.path.join(GOLDEN, "label_adapter_golden.json")))["vqa_accuracy"]
+    assert len(cases) >= 25
+    for c in cases:
+        assert abs(vqa_accuracy(c["answer"], c["gt_answers"]) - c["accuracy"]) <= 1e-6, c
+
+
+def test_certify_agent_scores_vqa_samples_by_answer_text(tmp_path):
+    """A dataset item whose label is a list of human answers is scored with the VQA accuracy of the certified class's answer text."""
+    from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
+
+    class TextEngine(Engine):
+        label_map = AnswerLabelMap(5, ["a cat", "no", "2 dogs", "yes"])          # class 2 ("2 dogs") wins 90 % of the votes
+
+    cfg = _config(tmp_path, "image_text_certify")
+    registry.register("configuration", cfg)
+    agent = setup_agent(cfg)
+    agent.classifier = TextEngine()
+    gts = ["two dogs"] * 2 + ["2 dogs"] * 2 + ["dogs"] * 6
+    agent.dataset = [(torch.zeros(3, 8, 8), gts), (torch.zeros(3, 8, 8), ["yes"] * 10)]
+    agent.run()
+    recs = agent.records
+    assert recs[0]["answer"] == "2 dogs" and abs(recs[0]["correct"] - 0.6) < 1e-9    # "2 dogs" matches 2 of the processed answers
+    assert recs[1]["correct"] == 0.0
+    res = agent.finalize()
+    assert abs(res["accuracy"] - 0.3) < 1e-9 and abs(res["certified_acc@0.25"] - 0.3) < 1e-9
