@@ -313,12 +313,6 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         CGPT_ASTAMP(2)                                   // V -> LDS (incl. waiting for its loads) + barrier
         // the staging registers are free: request the NEXT item's K now; it lands during the rest of this item
         if (item + (int)gridDim.x < nitems) request_kv(item + gridDim.x, false);
-#ifdef CGPT_ATTN_STAGGER
-        // experiment: the two waves of a SIMD (w, w + 4) run the same program in lockstep -- both in QK^T, both in the softmax, both in
-        // P.V -- so the matrix pipe idles during the softmax and the VALU during the MFMA phases.  Delay waves 4-7 by about half a
-        // tile after the V barrier (s_sleep n = 64 n cycles) so that one wave's softmax runs under its partner's MFMAs.
-        if (NWAVES == 8 && wave >= 4) __builtin_amdgcn_s_sleep(CGPT_ATTN_STAGGER);
-#endif
         if (have) pv_store(qt);
         CGPT_ASTAMP(3)                                   // first P.V + store
         for (qt += NWAVES; qt < nqt; qt += NWAVES) {
