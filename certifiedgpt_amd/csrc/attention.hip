@@ -336,211 +336,331 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
 
 
 // ------------------------------------------------------------------------------------------- streaming variant
-// Tk > 288 (448^2 images: T = 1025, the reference's own image size, minigpt4.py:32; eva_vit.py:383-404): K and V no longer
-// fit in LDS, so a workgroup owns 128 queries (one 16-query tile per wave) of one (sample, head) and streams the keys
-// through LDS in chunks of 288 with an online softmax.  With the transposed product O^T = V^T P^T the query sits on the
-// lane, so the running maximum m, the rescale factor alpha = 2^((m_old - m_new) scale log2e) and -- through the ones
+// Tk > 288 (448^2 images: T = 1025, the reference's own image size, minigpt4.py:32; eva_vit.py:383-404): K and V no longer fit in
+// LDS, so a workgroup owns 256 queries of one (sample, head) and streams the keys through LDS with an online softmax.  With the
+// transposed product O^T = V^T P^T the query sits on the lane, so the exponent reference, the rescale factor and -- through the ones
 // column of V -- the running denominator are all lane-local: a rescale is one multiply per accumulator register.
+//   * a wave owns TWO 16-query tiles, so every K and V fragment read from LDS feeds two MFMAs (round 1's form, 8 waves x 16 queries
+//     with 288-key chunks, re-read every fragment eight times: 600 of its 968 us at 64 samples x 16 heads x T = 1025 remained once
+//     its chunk loads and fragment reads were ablated away, profiles/r02/attention_stream.txt);
+//   * K / V chunks of 192 keys are double-buffered in LDS and filled by LDS-DMA (global_load_lds, 16 B per lane, the K image's
+//     chunk swizzle applied on the SOURCE side, pad chunks -- zeros for K, the ones column for V -- written once per kernel and
+//     never touched by the DMA): chunk c+1 is requested while chunk c computes; no staging registers, one barrier per chunk
+//     (before: load -> barrier -> compute -> barrier with every wave waiting for the loads, 222 us of the 968);
+//   * the keys of a chunk are walked in units of 32 (two key tiles = one P.V MFMA k-step) with an online softmax per unit, software-
+//     pipelined inside the wave: QK^T of unit u+1 is issued before the softmax of unit u (before: QK^T of 288 keys, then 72 exps per
+//     lane, then P.V);
+//   * the exponent reference lags the running maximum (see RESCALE_LOG2), so the 48 accumulator registers are rescaled a few times
+//     per pass instead of in nearly every unit.
+// Work order: the query blocks of one (sample, head) re-read the same K and V (360 KB at T = 1025).  Workgroups are dealt to the 8
+// XCDs round-robin by the hardware, so XCD x owns the pairs x, x+8, ... and its workgroups walk pair-major through their query blocks:
+// the workgroups of one XCD sit on a few pairs at a time and K / V come out of that XCD's L2 (a plain item = blockIdx walk fetched a
+// copy per XCD: HBM-bound at ~3.5 TB/s).
 template <int HD, int DPAD>
 __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NKT = 18, NT = 512;
+    constexpr int TKP = 192, UPC = TKP / 32;                                // keys per chunk, 32-key units per chunk
     constexpr int KROW = AttnLayout<DPAD>::KROW, VSTR = AttnLayout<DPAD>::VSTR;
-    constexpr int TKP = NKT * 16;
-    constexpr int CH = DPAD / 8, NDS = DPAD / 32, NDT = DPAD / 16;
-    constexpr int NV = (TKP * CH + NT - 1) / NT;
-    half_t* Ks = reinterpret_cast<half_t*>(smem_raw);
-    half_t* Vs = Ks + TKP * KROW;
+    constexpr int KC = KROW / 8, VC = VSTR / 8, DC = HD / 8;                // 16-byte slots per K row / V row, data chunks per row
+    constexpr int NDS = DPAD / 32, NDT = DPAD / 16;
+    constexpr int KSLOTS = TKP * KC, VSLOTS = TKP * VC;
+    constexpr int NREQ = (KSLOTS + VSLOTS) / 64;                            // LDS-DMA instructions per chunk (workgroup total)
+    static_assert(KSLOTS % 64 == 0 && VSLOTS % 64 == 0, "chunk images are whole 1-KiB requests");
+    constexpr int STAGE = TKP * (KROW + VSTR);                              // halfs per buffer: K image then V image
+    half_t* const smem = reinterpret_cast<half_t*>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, g = lane >> 4;
-    const int nqb = (p.Tq + 127) / 128;
+    const int nqb = (p.Tq + 255) / 256;
     const int nchunks = (p.Tk + TKP - 1) / TKP;
     const float sl2 = p.scale * 1.44269504088896340736f;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // Work order: the nqb query blocks of one (sample, head) re-read the same K and V (360 KB at T = 1025).  Workgroups are
-    // dealt to the 8 XCDs round-robin by the hardware, so with a plain item = blockIdx walk every query block of a head ran
-    // on a different XCD and fetched its own copy through a different L2 (measured: HBM-bound at ~3.5 TB/s).  Here XCD x
-    // owns the (sample, head) pairs x, x+8, ... and its workgroups walk pair-major through their query blocks, so the
-    // workgroups of one XCD sit on ~4 pairs at a time and K / V come out of that XCD's L2.
+    // pad slots of both buffers, once: K chunks >= DC are zero (q is zero there too, but 0 x stale-LDS NaN would not be), V chunk DC
+    // holds the ones column (DPAD > HD), the rest of a V row's tail is zero
+    for (int sidx = tid; sidx < 2 * TKP * (KC - DC + VC - DC); sidx += 512) {
+        const int buf = sidx / (TKP * (KC - DC + VC - DC)), rem = sidx % (TKP * (KC - DC + VC - DC));
+        const int row = rem / (KC - DC + VC - DC), k = rem % (KC - DC + VC - DC);
+        half_t* base = smem + buf * STAGE;
+        if (k < KC - DC) {
+            *reinterpret_cast<f16x8*>(base + row * KROW + k_chunk_pos<DPAD>(row, DC + k) * 8) = zero8;
+        } else {
+            const int c = DC + (k - (KC - DC));
+            f16x8 v = zero8;
+            if (DPAD > HD && c == DC) v[0] = (half_t)1.0f;
+            *reinterpret_cast<f16x8*>(base + TKP * KROW + row * VSTR + c * 8) = v;
+        }
+    }
+
+    // XCD x owns the (sample, head) pairs x, x+8, ... and walks them pair-major (see above)
     const int npairs = p.heads * p.B;
     const bool xcd_map = (gridDim.x & 7) == 0;
     const int xcd = xcd_map ? (int)(blockIdx.x & 7) : 0, nx = xcd_map ? 8 : 1;
     const int lid = xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, nl = xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
     const int my_pairs = (npairs - xcd + nx - 1) / nx;
-    for (int w = lid; w < my_pairs * nqb; w += nl) {
+    const int nwork = my_pairs * nqb;
+
+    // request chunk c of work item w into buffer `buf`: request r = wave + 8 i of the chunk covers slots 64 r .. 64 r + 63 of
+    // the buffer image (K slots first); a lane fetches the 16-byte chunk that belongs in ITS slot, pad slots are skipped.
+    // The slot -> (row, source chunk) decode does not depend on the chunk: one packed register per request, made once.
+    constexpr int NI = (NREQ + 7) / 8, KREQ = KSLOTS / 64;
+    int rowch[NI];                                                          // row << 8 | source chunk (>= DC: pad slot, no request)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = wave + 8 * i, slot = r * 64 + lane;
+        if (r < KREQ) { const int row = slot / KC; rowch[i] = row << 8 | k_chunk_pos<DPAD>(row, slot - row * KC); }   // the swizzle is an involution
+        else { const int sv = slot - KSLOTS, row = sv / VC; rowch[i] = row << 8 | (sv - row * VC); }
+    }
+    // The requests of a chunk are spread over the units of the previous chunk (request i in unit i % UPC): issued in one burst after
+    // the barrier, the workgroup's 78 KiB went through the CU's one address unit (64 B / clock) with all eight waves waiting for their
+    // turn -- 14 % of the kernel in the phase stamps.
+    int nw = 0, nc = 0;                                                     // the chunk being requested: work item, chunk
+    const half_t *nKg = nullptr, *nVg = nullptr;
+    auto set_next = [&](int w, int c) {
+        nw = w; nc = c;
+        const int pair = xcd + nx * (w / nqb);
+        const int h = pair % p.heads, b = pair / p.heads;
+        nKg = p.K + (int64_t)b * p.kv_batch_stride + h * HD;
+        nVg = p.V + (int64_t)b * p.kv_batch_stride + h * HD;
+    };
+    auto request_part = [&](int i, int buf) {                               // request i of this wave for chunk (nw, nc) into buffer `buf`
+        const int r = wave + 8 * i;                                        // wave-uniform
+        if (r >= NREQ || nw >= nwork) return;
+        const int ch = rowch[i] & 255;
+        const int grow = min(nc * TKP + (rowch[i] >> 8), p.Tk - 1);        // rows past the end: a valid row (its P is 0)
+        const half_t* src = (r < KREQ ? nKg : nVg) + (grow * (int)p.ldk + ch * 8);   // 32-bit offsets inside a sample (launch check)
+        half_t* dst = smem + buf * STAGE + r * 512;                        // 64 lanes x 8 halfs per request
+        if (ch < DC)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto request_unit = [&](int u, int buf) {                               // the requests that belong to unit u of the current chunk
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (i % UPC == u) request_part(i, buf);
+    };
+
+#ifdef CGPT_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long stamp_begin = __builtin_amdgcn_s_memtime();
+    unsigned long long tlast = stamp_begin;
+#define CGPT_S2STAMP(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += tn - tlast; tlast = tn; }
+#else
+#define CGPT_S2STAMP(k)
+#endif
+    int w = lid;
+    set_next(w, 0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) request_part(i, 0);
+    int buf = 0;
+    for (; w < nwork; w += nl) {
         const int pair = xcd + nx * (w / nqb), qb = w % nqb;
         const int h = pair % p.heads, b = pair / p.heads;
-        const half_t* Kg = p.K + (int64_t)b * p.kv_batch_stride + h * HD;
-        const half_t* Vg = p.V + (int64_t)b * p.kv_batch_stride + h * HD;
         const half_t* Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
         half_t* Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
-        const int qt = qb * 8 + wave;
-        const bool have = qt * 16 < p.Tq;
+        const int q0 = qb * 256 + wave * 32;                                // this wave's queries q0 .. q0 + 31 (tiles a, b)
+        const bool have = q0 < p.Tq;
 
-        f16x8 qf[NDS];
-        {
-            const int qrow = min(qt * 16 + r15, p.Tq - 1);
+        f16x8 qf[2][NDS];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qrow = min(q0 + t * 16 + r15, p.Tq - 1);
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
                 const int d = min(ds * 32 + g * 8, HD - 8);
                 const f16x8 v = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
-                qf[ds] = (ds * 32 + g * 8 < HD) ? v : zero8;
+                qf[t][ds] = (ds * 32 + g * 8 < HD) ? v : zero8;
             }
         }
-        f32x4 o[NDT];
+        f32x4 o[2][NDT];
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float m_run = -1e30f, l_run = 0.f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+        CGPT_S2STAMP(0)                                  // item set-up (Q loads issued)
 
-        for (int c = 0; c < nchunks; ++c) {
-            const int key0 = c * TKP;
-            const int nk = min(TKP, p.Tk - key0);
-            __syncthreads();                               // every wave is done with the previous chunk's images
-            {
-                f16x8 kreg[NV], vreg[NV];
-#pragma unroll
-                for (int it = 0; it < NV; ++it) {
-                    const int idx = tid + it * NT;
-                    const int row = key0 + min(idx / CH, nk - 1), ch = min(idx % CH, HD / 8 - 1);
-                    kreg[it] = *reinterpret_cast<const f16x8*>(Kg + (int64_t)row * p.ldk + ch * 8);
-                    vreg[it] = *reinterpret_cast<const f16x8*>(Vg + (int64_t)row * p.ldv + ch * 8);
-                }
-#pragma unroll
-                for (int it = 0; it < NV; ++it) {
-                    const int idx = tid + it * NT;
-                    const int row = idx / CH, ch = idx - row * CH;
-                    const bool valid = row < nk && ch * 8 < HD;
-                    f16x8 vv = valid ? vreg[it] : zero8;
-                    if (DPAD > HD && ch * 8 == HD) vv = f16x8{(half_t)1.0f, 0, 0, 0, 0, 0, 0, 0};
-                    if (idx < TKP * CH) {
-                        *reinterpret_cast<f16x8*>(Ks + row * KROW + k_chunk_pos<DPAD>(row, ch) * 8) = valid ? kreg[it] : zero8;
-                        *reinterpret_cast<f16x8*>(Vs + row * VSTR + ch * 8) = vv;
-                    }
-                }
-            }
+        for (int c = 0; c < nchunks; ++c, buf ^= 1) {
+            // this wave's requests for chunk c have landed; after the barrier everybody's have, and every wave is done with the
+            // other buffer (chunk c-1), which the next chunk's requests may now overwrite
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CGPT_S2STAMP(1)                              // waiting for this wave's requests of the chunk (and the item's Q)
             __syncthreads();
-            if (!have) continue;
+            CGPT_S2STAMP(2)                              // barrier
+            if (c + 1 < nchunks) set_next(w, c + 1);
+            else set_next(w + nl, 0);                      // (past the last work item: request_part does nothing)
+            if (!have) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) request_part(i, buf ^ 1);
+                continue;
+            }
+            CGPT_S2STAMP(3)
+            const half_t* Ks = smem + buf * STAGE;
+            const half_t* Vs = Ks + TKP * KROW;
+            const int key0 = c * TKP;
+            const int nu = min(UPC, (p.Tk - key0 + 31) / 32);             // units of this chunk that hold keys
 
-            // ---- S^T for this chunk
-            f32x4 s[NKT];
-            {
-                constexpr int KD = 2;
-                f16x8 kring[KD + 1][NDS];
-                auto kaddr = [&](int kt, int ds) {
-                    const int row = kt * 16 + r15;
-                    return Ks + row * KROW + k_chunk_pos<DPAD>(row, ds * 4 + g) * 8;
-                };
+            // K fragments of unit u: lane holds row 32u + 16kt + r15, chunk 4ds + g (swizzled)
+            auto read_k = [&](f16x8 (&kf)[2][NDS], int u) {
 #pragma unroll
-                for (int kt = 0; kt < KD; ++kt)
-#pragma unroll
-                    for (int ds = 0; ds < NDS; ++ds) kring[kt % (KD + 1)][ds] = *reinterpret_cast<const f16x8*>(kaddr(kt, ds));
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) {
-                    if (kt + KD < NKT) {
-#pragma unroll
-                        for (int ds = 0; ds < NDS; ++ds)
-                            kring[(kt + KD) % (KD + 1)][ds] = *reinterpret_cast<const f16x8*>(kaddr(kt + KD, ds));
-                    }
-                    CGPT_FENCE
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int kt = 0; kt < 2; ++kt) {
+                    const int row = u * 32 + kt * 16 + r15;
 #pragma unroll
                     for (int ds = 0; ds < NDS; ++ds)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kring[kt % (KD + 1)][ds], qf[ds], acc, 0, 0, 0);
-                    s[kt] = acc;
-                    CGPT_FENCE
+                        kf[kt][ds] = *reinterpret_cast<const f16x8*>(Ks + row * KROW + k_chunk_pos<DPAD>(row, ds * 4 + g) * 8);
                 }
-            }
-            // ---- online softmax (everything per query = per lane group r15)
-            float mx = -1e30f;
-            const int klim = nk - 4 * g;
+            };
+            auto qk = [&](f32x4 (&s)[2][2], const f16x8 (&kf)[2][NDS]) {
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                if (kt * 16 + 16 > nk) {
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kt * 16 + r >= klim) s[kt][r] = -1e30f;
-                }
+                    for (int kt = 0; kt < 2; ++kt) s[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);    // first chunk: 2^(-huge) = 0, O is 0 anyway
-            m_run = m_new;
-            const float mxs = m_new * sl2;
-            float sm = 0.f;
+                for (int ds = 0; ds < NDS; ++ds)                           // four independent chains, one k-step each per round
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, -mxs));
-                    s[kt][r] = e;
-                    if constexpr (DPAD == HD) sm += e;
-                }
-            if constexpr (DPAD == HD) {
-                sm += __shfl_xor(sm, 16);
-                sm += __shfl_xor(sm, 32);
-                l_run = l_run * alpha + sm;
-            }
+                        for (int kt = 0; kt < 2; ++kt)
+                            s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][ds], qf[t][ds], s[t][kt], 0, 0, 0);
+            };
+
+            // the chunk's units, fully unrolled (LDS offsets become immediates, the score registers ping-pong by unit parity)
+            f16x8 kf[2][NDS];
+            f32x4 sc[2][2][2];                                             // [unit parity][tile][key tile]
+            read_k(kf, 0);
+            qk(sc[0], kf);
+            read_k(kf, 1);
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
-            // ---- O^T += V^T P^T
-            {
-                const half_t* vbase = Vs + (4 * g + (r15 >> 2)) * VSTR + 4 * (r15 & 3);
-                constexpr int NU = NKT / 2;
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    f16x4 vr[NDT][2];
+            for (int u = 0; u < UPC; ++u) {
+                if (u >= nu) break;
+                f32x4 (&s_cur)[2][2] = sc[u & 1];
+                // V fragments of unit u (two transposed 4x16 reads per d-tile)
+                f16x4 vr[NDT][2];
+                {
+                    const half_t* vbase = Vs + (u * 32 + 4 * g + (r15 >> 2)) * VSTR + 4 * (r15 & 3);
 #pragma unroll
                     for (int dt = 0; dt < NDT; ++dt) {
-                        const half_t* a1 = vbase + (32 * u) * VSTR + dt * 16;
-                        vr[dt][0] = lds_read_tr16(a1);
-                        vr[dt][1] = lds_read_tr16(a1 + 16 * VSTR);
-                    }
-                    f16x8 pf;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        pf[j] = (half_t)s[2 * u][j];
-                        pf[4 + j] = (half_t)s[2 * u + 1][j];
-                    }
-#pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt) {
-                        const f16x8 vf = {vr[dt][0][0], vr[dt][0][1], vr[dt][0][2], vr[dt][0][3],
-                                          vr[dt][1][0], vr[dt][1][1], vr[dt][1][2], vr[dt][1][3]};
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                        vr[dt][0] = lds_read_tr16(vbase + dt * 16);
+                        vr[dt][1] = lds_read_tr16(vbase + 16 * VSTR + dt * 16);
                     }
                 }
+                request_unit(u, buf ^ 1);
+                // QK^T of the NEXT unit goes to the matrix pipe first ...
+                // (unconditionally inside the chunk: a conditional fragment read makes the compiler split the fp16 vectors into
+                // halves and re-pack them with v_perm in front of every MFMA; units past the end read valid LDS and are never used)
+                if (u + 1 < UPC) {
+                    qk(sc[(u + 1) & 1], kf);
+                    if (u + 2 < UPC) read_k(kf, u + 2);
+                }
+                // ... and this unit's softmax runs under it
+                const int kb = key0 + u * 32;
+                if (kb + 32 > p.Tk) {                                      // wave-uniform: the unit holds keys past the end
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (kb + kt * 16 + 4 * g + r >= p.Tk) s_cur[t][kt][r] = -1e30f;
+                }
+                // The exponent reference m_run is allowed to lag behind the running maximum by up to 2^RESCALE_LOG2 (P then
+                // reaches 256, far inside fp16; numerator and denominator use the same reference, so the quotient is unchanged):
+                // with 32 queries in a wave SOME query's maximum moves in almost every unit, and rescaling 48 accumulator
+                // registers each time was a quarter of the unit's VALU work.  Now it happens when a query's scores really
+                // outgrow the reference -- normally in a block's first unit only.
+                constexpr float RESCALE_LOG2 = 8.0f;
+                float mx[2];
+                bool need = false;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float m = fmaxf(fmaxf(fmaxf(s_cur[t][0][0], s_cur[t][0][1]), fmaxf(s_cur[t][0][2], s_cur[t][0][3])),
+                                    fmaxf(fmaxf(s_cur[t][1][0], s_cur[t][1][1]), fmaxf(s_cur[t][1][2], s_cur[t][1][3])));
+                    {   // the query's four lane groups: rows of 16 swapped pairwise, then the two halves of the wave
+                        const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+                        m = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+                        const auto c2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+                        m = fmaxf(__builtin_bit_cast(float, c2[0]), __builtin_bit_cast(float, c2[1]));
+                    }
+                    mx[t] = m;
+                    need = need || ((m - m_run[t]) * sl2 > RESCALE_LOG2);
+                }
+                if (__builtin_amdgcn_ballot_w64(need) != 0) {              // wave-uniform
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float m_new = fmaxf(m_run[t], mx[t]);
+                        const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * sl2);   // first unit: 0 (o is 0)
+                        if constexpr (DPAD == HD) l_run[t] *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < NDT; ++dt) o[t][dt] *= alpha;
+                        m_run[t] = m_new;
+                    }
+                }
+                f16x8 pf[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float mxs = m_run[t] * sl2;
+                    float e[8];
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) e[kt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s_cur[t][kt][r], sl2, -mxs));
+                    if constexpr (DPAD == HD) l_run[t] += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[t][j] = (half_t)e[j];
+                }
+                // O^T += V^T P^T for both tiles
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const f16x8 vf = __builtin_shufflevector(vr[dt][0], vr[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t], o[t][dt], 0, 0, 0);
+                }
             }
+#pragma unroll
+            for (int u = 1; u < UPC; ++u)
+                if (u >= nu) request_unit(u, buf ^ 1);    // a short last chunk: the shares of the units it does not have
+            CGPT_S2STAMP(4)                              // the chunk's units
         }
         if (have) {
-            float den = l_run;
-            if constexpr (DPAD > HD) {
-                constexpr int DT = HD / 16, GG = (HD % 16) / 4, RR = (HD % 16) % 4;
-                den = __shfl(o[DT][RR], 16 * GG + r15);
-            }
-            const float inv = 1.0f / den;
-            const int q = qt * 16 + r15;
-            // pairs of d-tiles exchanged with v_permlane16_swap -> 16-byte stores (see attention_kernel's pv_store)
 #pragma unroll
-            for (int dp = 0; dp < NDT / 2; ++dp) {
-                const int da = 2 * dp, db = 2 * dp + 1;
-                const f16x4 ha = {(half_t)(o[da][0] * inv), (half_t)(o[da][1] * inv), (half_t)(o[da][2] * inv), (half_t)(o[da][3] * inv)};
-                const f16x4 hb = {(half_t)(o[db][0] * inv), (half_t)(o[db][1] * inv), (half_t)(o[db][2] * inv), (half_t)(o[db][3] * inv)};
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const u32x2 ua = __builtin_bit_cast(u32x2, ha), ub = __builtin_bit_cast(u32x2, hb);
-                const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                const u32x4 packed = {s0[0], s1[0], s0[1], s1[1]};
-                const int d0 = ((g & 1) ? db : da) * 16 + (g >> 1) * 8;
-                if (q < p.Tq && d0 < HD) *reinterpret_cast<u32x4*>(Ob + (int64_t)q * p.ldo + d0) = packed;
+            for (int t = 0; t < 2; ++t) {
+                float den;
+                if constexpr (DPAD > HD) {
+                    constexpr int DT = HD / 16, GG = (HD % 16) / 4, RR = (HD % 16) % 4;
+                    den = __shfl(o[t][DT][RR], 16 * GG + r15);
+                } else {
+                    den = l_run[t];
+                    den += __shfl_xor(den, 16);
+                    den += __shfl_xor(den, 32);
+                }
+                const float inv = 1.0f / den;
+                const int q = q0 + t * 16 + r15;
+#pragma unroll
+                for (int dp = 0; dp < NDT / 2; ++dp) {
+                    const int da = 2 * dp, db = 2 * dp + 1;
+                    const f16x4 ha = {(half_t)(o[t][da][0] * inv), (half_t)(o[t][da][1] * inv), (half_t)(o[t][da][2] * inv), (half_t)(o[t][da][3] * inv)};
+                    const f16x4 hb = {(half_t)(o[t][db][0] * inv), (half_t)(o[t][db][1] * inv), (half_t)(o[t][db][2] * inv), (half_t)(o[t][db][3] * inv)};
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x2 ua = __builtin_bit_cast(u32x2, ha), ub = __builtin_bit_cast(u32x2, hb);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                    const u32x4 packed = {s0[0], s1[0], s0[1], s1[1]};
+                    const int d0 = ((g & 1) ? db : da) * 16 + (g >> 1) * 8;
+                    if (q < p.Tq && d0 < HD) *reinterpret_cast<u32x4*>(Ob + (int64_t)q * p.ldo + d0) = packed;
+                }
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CGPT_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        d[0] = __builtin_amdgcn_s_memtime() - stamp_begin;
+        for (int k = 0; k < 6; ++k) d[1 + k] = ph[k];
+    }
+#endif
 }
 
 
@@ -561,7 +681,7 @@ inline hipError_t device_cus(int& dev, int& cus) {
 
 template <int HD, int DPAD>
 hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
-    constexpr int lds_bytes = 18 * 16 * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
+    constexpr int lds_bytes = 2 * 192 * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
     int dev = 0, num_cus = 0;
     if (hipError_t e = device_cus(dev, num_cus); e != hipSuccess) return e;
     static bool configured[kMaxDevicesA] = {false};
@@ -570,7 +690,7 @@ hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
             e != hipSuccess) return e;
         configured[dev] = true;
     }
-    const int items = p.heads * p.B * ((p.Tq + 127) / 128);
+    const int items = p.heads * p.B * ((p.Tq + 255) / 256);
     int grid = items < num_cus ? items : num_cus;
     if (grid >= 8) grid &= ~7;                      // a multiple of 8 enables the XCD-aware work order
     hipLaunchKernelGGL((attention_stream_kernel<HD, DPAD>), dim3(grid), dim3(512), lds_bytes, stream, p);
@@ -606,7 +726,7 @@ hipError_t launch_attention(const AttnParams& p_in, hipStream_t stream) {
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 8)) return hipErrorInvalidValue;   // 16-byte row alignment
     if (p.ldk != p.ldv || p.Tk * p.ldk >= (1ll << 30) || p.Tq * p.ldq >= (1ll << 30)) return hipErrorInvalidValue;   // 32-bit offsets within a sample
     const bool small = p.Tk <= 32;
-    if (p.Tk > 288) {                               // K/V streamed through LDS in 288-key chunks (448^2 images)
+    if (p.Tk > 288) {                               // K/V streamed through LDS in 192-key chunks (448^2 images)
         if (p.head_dim == 88) return launch_stream<88, 96>(p, stream);
         if (p.head_dim == 64) return launch_stream<64, 64>(p, stream);
         return hipErrorInvalidValue;
