@@ -356,10 +356,10 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
 // XCDs round-robin by the hardware, so XCD x owns the pairs x, x+8, ... and its workgroups walk pair-major through their query blocks:
 // the workgroups of one XCD sit on a few pairs at a time and K / V come out of that XCD's L2 (a plain item = blockIdx walk fetched a
 // copy per XCD: HBM-bound at ~3.5 TB/s).
-template <int HD, int DPAD>
+template <int HD, int DPAD, int TKP>
 __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int TKP = 192, UPC = TKP / 32;                                // keys per chunk, 32-key units per chunk
+    constexpr int UPC = TKP / 32;                                           // TKP keys per chunk = UPC units of 32 keys
     constexpr int KROW = AttnLayout<DPAD>::KROW, VSTR = AttnLayout<DPAD>::VSTR;
     constexpr int KC = KROW / 8, VC = VSTR / 8, DC = HD / 8;                // 16-byte slots per K row / V row, data chunks per row
     constexpr int NDS = DPAD / 32, NDT = DPAD / 16;
@@ -449,6 +449,24 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
 #else
 #define CGPT_S2STAMP(k)
 #endif
+    // Q^T B-fragments of work item w's two tiles: lane holds Q[query r15][d = 32 ds + 8 g .. +7] (zero beyond HD).  They are requested
+    // in the LAST unit of the previous item -- every QK^T of that item has been issued by then -- so the load latency sits under that
+    // unit's softmax and P.V and the epilogue instead of in front of the item's first QK^T.
+    f16x8 qf[2][NDS];
+    auto load_q = [&](int wi) {
+        const int pair = xcd + nx * (wi / nqb), qb = wi % nqb;
+        const half_t* Qb = p.Q + (int64_t)(pair / p.heads) * p.q_batch_stride + (pair % p.heads) * HD;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qrow = min(qb * 256 + wave * 32 + t * 16 + r15, p.Tq - 1);
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                const int d = min(ds * 32 + g * 8, HD - 8);
+                const f16x8 v = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
+                qf[t][ds] = (ds * 32 + g * 8 < HD) ? v : zero8;
+            }
+        }
+    };
     int w = lid;
     set_next(w, 0);
 #pragma unroll
@@ -457,22 +475,11 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     for (; w < nwork; w += nl) {
         const int pair = xcd + nx * (w / nqb), qb = w % nqb;
         const int h = pair % p.heads, b = pair / p.heads;
-        const half_t* Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
         half_t* Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
         const int q0 = qb * 256 + wave * 32;                                // this wave's queries q0 .. q0 + 31 (tiles a, b)
         const bool have = q0 < p.Tq;
 
-        f16x8 qf[2][NDS];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int qrow = min(q0 + t * 16 + r15, p.Tq - 1);
-#pragma unroll
-            for (int ds = 0; ds < NDS; ++ds) {
-                const int d = min(ds * 32 + g * 8, HD - 8);
-                const f16x8 v = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
-                qf[t][ds] = (ds * 32 + g * 8 < HD) ? v : zero8;
-            }
-        }
+        if (w == lid) load_q(w);                                            // later items: requested in the previous item's last unit
         f32x4 o[2][NDT];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -493,6 +500,7 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
             if (!have) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) request_part(i, buf ^ 1);
+                if (c + 1 == nchunks && w + nl < nwork) load_q(w + nl);
                 continue;
             }
             CGPT_S2STAMP(3)
@@ -550,9 +558,10 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                 // (unconditionally inside the chunk: a conditional fragment read makes the compiler split the fp16 vectors into
                 // halves and re-pack them with v_perm in front of every MFMA; units past the end read valid LDS and are never used)
                 if (u + 1 < UPC) {
-                    qk(sc[(u + 1) & 1], kf);
+                    if (u + 1 < nu) qk(sc[(u + 1) & 1], kf);
                     if (u + 2 < UPC) read_k(kf, u + 2);
                 }
+                if (c + 1 == nchunks && u + 1 == nu && w + nl < nwork) load_q(w + nl);   // this item's last QK^T has been issued
                 // ... and this unit's softmax runs under it
                 const int kb = key0 + u * 32;
                 if (kb + 32 > p.Tk) {                                      // wave-uniform: the unit holds keys past the end
@@ -679,21 +688,21 @@ inline hipError_t device_cus(int& dev, int& cus) {
     return hipSuccess;
 }
 
-template <int HD, int DPAD>
+template <int HD, int DPAD, int TKP>
 hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
-    constexpr int lds_bytes = 2 * 192 * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
+    constexpr int lds_bytes = 2 * TKP * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
     int dev = 0, num_cus = 0;
     if (hipError_t e = device_cus(dev, num_cus); e != hipSuccess) return e;
     static bool configured[kMaxDevicesA] = {false};
     if (!configured[dev]) {
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_stream_kernel<HD, DPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_stream_kernel<HD, DPAD, TKP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             e != hipSuccess) return e;
         configured[dev] = true;
     }
     const int items = p.heads * p.B * ((p.Tq + 255) / 256);
     int grid = items < num_cus ? items : num_cus;
     if (grid >= 8) grid &= ~7;                      // a multiple of 8 enables the XCD-aware work order
-    hipLaunchKernelGGL((attention_stream_kernel<HD, DPAD>), dim3(grid), dim3(512), lds_bytes, stream, p);
+    hipLaunchKernelGGL((attention_stream_kernel<HD, DPAD, TKP>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
@@ -727,8 +736,8 @@ hipError_t launch_attention(const AttnParams& p_in, hipStream_t stream) {
     if (p.ldk != p.ldv || p.Tk * p.ldk >= (1ll << 30) || p.Tq * p.ldq >= (1ll << 30)) return hipErrorInvalidValue;   // 32-bit offsets within a sample
     const bool small = p.Tk <= 32;
     if (p.Tk > 288) {                               // K/V streamed through LDS in 192-key chunks (448^2 images)
-        if (p.head_dim == 88) return launch_stream<88, 96>(p, stream);
-        if (p.head_dim == 64) return launch_stream<64, 64>(p, stream);
+        if (p.head_dim == 88) return launch_stream<88, 96, 192>(p, stream);
+        if (p.head_dim == 64) return launch_stream<64, 64, 192>(p, stream);
         return hipErrorInvalidValue;
     }
     if (p.head_dim == 88) return small ? launch_one<88, 96, 2, 128>(p, stream) : launch_one<88, 96, 18, 512>(p, stream);
