@@ -376,6 +376,12 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     const int nchunks = (p.Tk + TKP - 1) / TKP;
     const float sl2 = p.scale * 1.44269504088896340736f;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // FOLD (a pad column exists, DPAD > HD): the scores leave the MFMA ready for exp2 -- Q is scaled by scale * log2 e when it is loaded
+    // (fp32 multiply, one rounding to fp16; the reference scales q in fp16 too, eva_vit.py:140), and the exponent reference rides in the
+    // pad column: K's image holds 1 at d = HD, the Q fragment -reference.  That takes the 16 v_fma per unit (s * scale - reference) out
+    // of the softmax, a tenth of the unit's vector-issue cycles.
+    constexpr bool FOLD = DPAD > HD;
+    constexpr float RESCALE_LOG2 = 8.0f;
 
     // pad slots of both buffers, once: K chunks >= DC are zero (q is zero there too, but 0 x stale-LDS NaN would not be), V chunk DC
     // holds the ones column (DPAD > HD), the rest of a V row's tail is zero
@@ -384,7 +390,9 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
         const int row = rem / (KC - DC + VC - DC), k = rem % (KC - DC + VC - DC);
         half_t* base = smem + buf * STAGE;
         if (k < KC - DC) {
-            *reinterpret_cast<f16x8*>(base + row * KROW + k_chunk_pos<DPAD>(row, DC + k) * 8) = zero8;
+            f16x8 v = zero8;
+            if (FOLD && k == 0) v[0] = (half_t)1.0f;                       // the column that adds the Q fragment's -reference
+            *reinterpret_cast<f16x8*>(base + row * KROW + k_chunk_pos<DPAD>(row, DC + k) * 8) = v;
         } else {
             const int c = DC + (k - (KC - DC));
             f16x8 v = zero8;
@@ -462,8 +470,12 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
                 const int d = min(ds * 32 + g * 8, HD - 8);
-                const f16x8 v = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
-                qf[t][ds] = (ds * 32 + g * 8 < HD) ? v : zero8;
+                f16x8 v = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
+                if constexpr (FOLD) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * sl2);
+                }
+                qf[t][ds] = (ds * 32 + g * 8 < HD) ? v : zero8;       // (FOLD: element 0 of the d = HD chunk is the -reference, 0 at first)
             }
         }
     };
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+        float m_run[2] = {FOLD ? 0.f : -1e30f, FOLD ? 0.f : -1e30f}, l_run[2] = {0.f, 0.f};   // exponent reference (FOLD: in log2 units, fp16-exact)
         CGPT_S2STAMP(0)                                  // item set-up (Q loads issued)
 
         for (int c = 0; c < nchunks; ++c, buf ^= 1) {
@@ -573,18 +585,18 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                             for (int r = 0; r < 4; ++r)
                                 if (kb + kt * 16 + 4 * g + r >= p.Tk) s_cur[t][kt][r] = -1e30f;
                 }
-                // The exponent reference m_run is allowed to lag behind the running maximum by up to 2^RESCALE_LOG2 (P then
-                // reaches 256, far inside fp16; numerator and denominator use the same reference, so the quotient is unchanged):
-                // with 32 queries in a wave SOME query's maximum moves in almost every unit, and rescaling 48 accumulator
-                // registers each time was a quarter of the unit's VALU work.  Now it happens when a query's scores really
-                // outgrow the reference -- normally in a block's first unit only.
-                constexpr float RESCALE_LOG2 = 8.0f;
+                // The exponent reference is allowed to lag behind the running maximum by up to 2^RESCALE_LOG2 (P then reaches 256,
+                // far inside fp16; numerator and denominator use the same reference, so the quotient is unchanged): with 32 queries
+                // in a wave SOME query's maximum moves in almost every unit, and rescaling 48 accumulator registers each time was a
+                // quarter of the unit's VALU work.  Now it happens when a query's scores really outgrow the reference -- normally in
+                // a block's first unit only.  The reference never exceeds the running maximum, so the largest P is >= 1.
                 float mx[2];
-                bool need = false;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    float m = fmaxf(fmaxf(fmaxf(s_cur[t][0][0], s_cur[t][0][1]), fmaxf(s_cur[t][0][2], s_cur[t][0][3])),
-                                    fmaxf(fmaxf(s_cur[t][1][0], s_cur[t][1][1]), fmaxf(s_cur[t][1][2], s_cur[t][1][3])));
+                    float m = fmaxf(fmaxf(s_cur[t][0][0], s_cur[t][0][1]), s_cur[t][0][2]);                  // v_max3 x 3 + v_max
+                    const float m2 = fmaxf(fmaxf(s_cur[t][0][3], s_cur[t][1][0]), s_cur[t][1][1]);
+                    m = fmaxf(fmaxf(s_cur[t][1][2], s_cur[t][1][3]), m);
+                    m = fmaxf(m, m2);
                     {   // the query's four lane groups: rows of 16 swapped pairwise, then the two halves of the wave
                         const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
                         m = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
@@ -592,31 +604,69 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                         m = fmaxf(__builtin_bit_cast(float, c2[0]), __builtin_bit_cast(float, c2[1]));
                     }
                     mx[t] = m;
-                    need = need || ((m - m_run[t]) * sl2 > RESCALE_LOG2);
-                }
-                if (__builtin_amdgcn_ballot_w64(need) != 0) {              // wave-uniform
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const float m_new = fmaxf(m_run[t], mx[t]);
-                        const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * sl2);   // first unit: 0 (o is 0)
-                        if constexpr (DPAD == HD) l_run[t] *= alpha;
-#pragma unroll
-                        for (int dt = 0; dt < NDT; ++dt) o[t][dt] *= alpha;
-                        m_run[t] = m_new;
-                    }
                 }
                 f16x8 pf[2];
+                if constexpr (FOLD) {
+                    // scores are (q . k) scale log2 e - reference already
+                    const bool first = c == 0 && u == 0;                   // wave-uniform: no reference yet (it is 0, o is 0)
+                    if (first || __builtin_amdgcn_ballot_w64(mx[0] > RESCALE_LOG2 || mx[1] > RESCALE_LOG2) != 0) {
+                        const bool nxt = u + 1 < UPC && u + 1 < nu;        // the next unit's scores exist and carry the old reference
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float mxs = m_run[t] * sl2;
-                    float e[8];
+                        for (int t = 0; t < 2; ++t) {
+                            const float ref_new = (float)(half_t)(m_run[t] + (first ? mx[t] : fmaxf(mx[t], 0.f)));   // what the fragment can hold
+                            const float d = ref_new - m_run[t];
+                            m_run[t] = ref_new;
+                            // (not in the item's last unit: no QK^T follows, and qf may already belong to the next item)
+                            if (g == 3 && !(c + 1 == nchunks && u + 1 == nu)) qf[t][NDS - 1][0] = (half_t)(-ref_new);
+                            if (!first) {
+                                const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
+                                for (int dt = 0; dt < NDT; ++dt) o[t][dt] *= alpha;
+                            }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) e[kt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s_cur[t][kt][r], sl2, -mxs));
-                    if constexpr (DPAD == HD) l_run[t] += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+                            for (int kt = 0; kt < 2; ++kt) {
+                                s_cur[t][kt] -= d;
+                                if (nxt) sc[(u + 1) & 1][t][kt] -= d;
+                            }
+                        }
+                    }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[t][j] = (half_t)e[j];
+                    for (int t = 0; t < 2; ++t) {
+                        float e[8];
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) e[kt * 4 + r] = __builtin_amdgcn_exp2f(s_cur[t][kt][r]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pf[t][j] = (half_t)e[j];
+                    }
+                } else {
+                    bool need = false;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) need = need || ((mx[t] - m_run[t]) * sl2 > RESCALE_LOG2);
+                    if (__builtin_amdgcn_ballot_w64(need) != 0) {          // wave-uniform
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const float m_new = fmaxf(m_run[t], mx[t]);
+                            const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * sl2);   // first unit: 0 (o is 0)
+                            l_run[t] *= alpha;
+#pragma unroll
+                            for (int dt = 0; dt < NDT; ++dt) o[t][dt] *= alpha;
+                            m_run[t] = m_new;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float mxs = m_run[t] * sl2;
+                        float e[8];
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) e[kt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s_cur[t][kt][r], sl2, -mxs));
+                        l_run[t] += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pf[t][j] = (half_t)e[j];
+                    }
                 }
                 // O^T += V^T P^T for both tiles
 #pragma unroll
