@@ -597,11 +597,15 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                     const float m2 = fmaxf(fmaxf(s_cur[t][0][3], s_cur[t][1][0]), s_cur[t][1][1]);
                     m = fmaxf(fmaxf(s_cur[t][1][2], s_cur[t][1][3]), m);
                     m = fmaxf(m, m2);
-                    {   // the query's four lane groups: rows of 16 swapped pairwise, then the two halves of the wave
+                    {   // the query's four lane groups: rows of 16 swapped pairwise, then the two halves of the wave.  The swap's
+                        // results go through scalars: __builtin_bit_cast applied to an ELEMENT of the returned vector reads element 0
+                        // for both (hipcc 7.2), which silently reduced the maximum over lane group 0 only.
                         const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
-                        m = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+                        const unsigned a0 = a[0], a1 = a[1];
+                        m = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
                         const auto c2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
-                        m = fmaxf(__builtin_bit_cast(float, c2[0]), __builtin_bit_cast(float, c2[1]));
+                        const unsigned c0 = c2[0], c1 = c2[1];
+                        m = fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
                     }
                     mx[t] = m;
                 }

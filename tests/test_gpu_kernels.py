@@ -133,9 +133,12 @@ def attn_ref(q, k, v, heads, hd, scale):
 @pytest.mark.parametrize("B,heads,hd,Tq,Tk", [(3, 2, 88, 257, 257), (2, 16, 88, 257, 257), (2, 2, 88, 17, 17),
                                                (3, 12, 64, 32, 257), (2, 12, 64, 32, 32), (2, 2, 64, 8, 17),
                                                (1, 2, 64, 8, 8), (1, 1, 88, 1, 1),
-                                               # Tk > 288: K/V streamed through LDS in 288-key chunks (448^2 images, T = 1025)
+                                               # Tk > 288: K/V streamed through LDS in 192-key chunks (448^2 images, T = 1025)
                                                (2, 2, 88, 401, 401), (1, 16, 88, 1025, 1025), (2, 12, 64, 32, 1025),
-                                               (1, 2, 88, 130, 300), (1, 2, 64, 289, 289), (1, 1, 88, 1, 577)])
+                                               (1, 2, 88, 130, 300), (1, 2, 64, 289, 289), (1, 1, 88, 1, 577),
+                                               # ... more work items than workgroups (requests and Q of the NEXT item issued inside the
+                                               # current one), chunk / unit boundaries (Tk = 2 x 192 + 1, 2 x 192), three query blocks
+                                               (24, 16, 88, 577, 577), (40, 12, 64, 300, 400), (3, 5, 88, 257, 385), (2, 3, 88, 700, 384)])
 def test_attention_matches_fp32_reference(B, heads, hd, Tq, Tk):
     L = cg.lib()
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + Tq + Tk)
@@ -155,6 +158,33 @@ def test_attention_matches_fp32_reference(B, heads, hd, Tq, Tk):
     ref = attn_ref(q[..., :D], k[..., :D], v[..., :D], heads, hd, scale)
     got = od.cpu().float()[..., :D]
     report(f"attention B{B} h{heads} d{hd} {Tq}x{Tk}", got.reshape(B * Tq, D), ref.reshape(B * Tq, D), 6e-3)
+
+
+@pytest.mark.parametrize("hd", [88, 64])
+def test_streaming_attention_rising_scores_rescale_path(hd):
+    """Streaming kernel (Tk > 288): the exponent reference lags the running maximum and is moved when a query's scores outgrow it by
+    2^8.  Here the scores of every query RISE along the keys (k_j = j / Tk * c * q-direction + noise): the reference moves many times,
+    in the middle of chunks as well as at their first unit, with the next unit's scores already computed against the old reference
+    (head_dim 88) -- and, for head_dim 64, through the unfolded form with its VALU row sums."""
+    L = cg.lib()
+    B, heads, Tq, Tk = 2, 3, 300, 700
+    g = torch.Generator(device="cpu").manual_seed(hd)
+    D = heads * hd
+    q = torch.randn(B, Tq, D, generator=g)
+    direction = torch.nn.functional.normalize(torch.randn(B, 1, heads, hd, generator=g), dim=-1)
+    q = (q.view(B, Tq, heads, hd) * 0.2 + direction * 6.0).reshape(B, Tq, D).half()
+    ramp = torch.linspace(0.0, 1.0, Tk).view(1, Tk, 1, 1)
+    k = (direction * ramp * 160.0 + torch.randn(B, Tk, heads, hd, generator=g) * 0.5).reshape(B, Tk, D).half()     # logits 0 .. ~100
+    v = torch.randn(B, Tk, D, generator=g).half()
+    scale = hd ** -0.5
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    od = torch.full((B, Tq, D), float("nan"), device=DEV, dtype=torch.float16)
+    _lib.check(L.cgpt_attention_f16(P(qd), D, P(kd), P(vd), D, P(od), D, B, heads, hd, Tq, Tk, scale, stream()))
+    torch.cuda.synchronize()
+    ref = attn_ref(q, k, v, heads, hd, scale)
+    logits = (q.float().view(B, Tq, heads, hd)[:, 0] * k.float().view(B, Tk, heads, hd)[:, -1]).sum(-1) * scale
+    assert float(logits.min()) > 40.0                                     # the ramp really spans many rescale thresholds
+    report(f"streaming attention, rising scores, d{hd}", od.cpu().float().reshape(B * Tq, D), ref.reshape(B * Tq, D), 6e-3)
 
 
 @pytest.mark.parametrize("rows,D", [(5, 176), (7, 128), (33, 768), (257, 1408), (3, 4096)])
