@@ -374,6 +374,8 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     const int r15 = lane & 15, g = lane >> 4;
     const int nqb = (p.Tq + 255) / 256;
     const int nchunks = (p.Tk + TKP - 1) / TKP;
+    // balanced chunks: CK keys each (a multiple of 32, <= TKP), so that every chunk's compute covers the next chunk's load
+    const int CK = ((p.Tk + 31) / 32 + nchunks - 1) / nchunks * 32;
     const float sl2 = p.scale * 1.44269504088896340736f;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     // FOLD (a pad column exists, DPAD > HD): the scores leave the MFMA ready for exp2 -- Q is scaled by scale * log2 e when it is loaded
@@ -420,9 +422,9 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
         if (r < KREQ) { const int row = slot / KC; rowch[i] = row << 8 | k_chunk_pos<DPAD>(row, slot - row * KC); }   // the swizzle is an involution
         else { const int sv = slot - KSLOTS, row = sv / VC; rowch[i] = row << 8 | (sv - row * VC); }
     }
-    // The requests of a chunk are spread over the units of the previous chunk (request i in unit i % UPC): issued in one burst after
-    // the barrier, the workgroup's 78 KiB went through the CU's one address unit (64 B / clock) with all eight waves waiting for their
-    // turn -- 14 % of the kernel in the phase stamps.
+    // The requests of a chunk are issued inside the first two units of the previous chunk (request i in unit i % 2): issued in one
+    // burst after the barrier, the workgroup's 78 KiB went through the CU's one address unit (64 B / clock) with all eight waves
+    // waiting for their turn -- 14 % of the kernel in the phase stamps; issued any later they have less time to land.
     int nw = 0, nc = 0;                                                     // the chunk being requested: work item, chunk
     const half_t *nKg = nullptr, *nVg = nullptr;
     auto set_next = [&](int w, int c) {
@@ -436,17 +438,17 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
         const int r = wave + 8 * i;                                        // wave-uniform
         if (r >= NREQ || nw >= nwork) return;
         const int ch = rowch[i] & 255;
-        const int grow = min(nc * TKP + (rowch[i] >> 8), p.Tk - 1);        // rows past the end: a valid row (its P is 0)
+        const int grow = min(nc * CK + (rowch[i] >> 8), p.Tk - 1);         // rows past the end: a valid row (its P is 0)
         const half_t* src = (r < KREQ ? nKg : nVg) + (grow * (int)p.ldk + ch * 8);   // 32-bit offsets inside a sample (launch check)
         half_t* dst = smem + buf * STAGE + r * 512;                        // 64 lanes x 8 halfs per request
-        if (ch < DC)
+        if (ch < DC && (rowch[i] >> 8) < CK)                                // (rows of the buffer a balanced chunk does not use: no request)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
     auto request_unit = [&](int u, int buf) {                               // the requests that belong to unit u of the current chunk
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            if (i % UPC == u) request_part(i, buf);
+            if (i % 2 == u) request_part(i, buf);                           // all of them in the chunk's first two units
     };
 
 #ifdef CGPT_STAMPS
@@ -518,8 +520,8 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
             CGPT_S2STAMP(3)
             const half_t* Ks = smem + buf * STAGE;
             const half_t* Vs = Ks + TKP * KROW;
-            const int key0 = c * TKP;
-            const int nu = min(UPC, (p.Tk - key0 + 31) / 32);             // units of this chunk that hold keys
+            const int key0 = c * CK;
+            const int nu = min(CK / 32, (p.Tk - key0 + 31) / 32);         // units of this chunk that hold keys
 
             // K fragments of unit u: lane holds row 32u + 16kt + r15, chunk 4ds + g (swizzled)
             auto read_k = [&](f16x8 (&kf)[2][NDS], int u) {
