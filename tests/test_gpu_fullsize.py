@@ -175,3 +175,32 @@ def test_full_size_encode_img_config0_certify_matches_cpu_oracle(encode_img_pair
     x = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
     out = _certify_both(clf, cfg, params, x, 10, 10, 0.25, 0.001, 42)
     _check_certify("encode_img config0", *out, 10, 0.001, 0.25)
+
+
+# ------------------------------------------------------------------ ViT-G at the reference's own image size (448 x 448, T = 1025)
+def test_vitg_448_streaming_attention_matches_cpu_oracle():
+    """SURVEY 8(f) rank 3 at full size: ViT-G + head on one noisy 448 x 448 sample (T = 1025 tokens, minigpt4.py:32 -- K / V no longer
+    fit in LDS, every block runs the streaming attention kernel), stage and logits against the fp32 CPU oracle on the same weights and
+    input.  CPU cost: one 2.25-TFLOP forward (~20-40 s on 16 cores)."""
+    import dataclasses
+    cfg = dataclasses.replace(mo.Config(mode=mo.MODE_VIT_HEAD, num_classes=K), img_size=448)
+    assert cfg.tokens == 1025
+    clf = make_classifier(cfg, max_batch=2)
+    try:
+        clf.init_synthetic(seed=0)
+        params = _device_params(clf, cfg)
+        torch.set_num_threads(_cores())
+        x = torch.from_numpy(mo.synthetic_image(cfg, seed=5)).to(DEV)
+        noisy = cg.noise_batch(x, 0, 1, 0.5, 42)
+        logits = clf(noisy).cpu()
+        t0 = time.perf_counter()
+        ref = mo.forward_all(params, noisy.cpu(), cfg)
+        print(f"  cpu oracle forward of one 448 x 448 sample: {time.perf_counter() - t0:.1f} s", flush=True)
+        e_vit = rel_err(clf.activation("vit_out", 1), ref["vit_out"])
+        e_log = rel_err(logits, ref["logits"])
+        print(f"[vitg 448] rel err vit_out {e_vit:.2e} logits {e_log:.2e}")
+        assert ref["vit_out"].shape == (1, 1025, 1408)
+        assert e_vit <= 2e-2 and e_log <= 2e-2, (e_vit, e_log)
+        assert int(logits.argmax()) == int(ref["logits"].argmax()) or float(ref["logits"].topk(2).values.diff().abs()) <= MARGIN * float(ref["logits"].abs().max())
+    finally:
+        clf.close()
