@@ -3,9 +3,11 @@
 
 Only tests may import this.  It follows the reference statement by statement (one context embedding per sample, left
 padding into a zero tensor, Hugging Face `generate` with the reference's fixed arguments, the same decode clean-up); the
-product (certifiedgpt_amd/minigpt4.py) embeds a shared prompt once and broadcasts it.  Pinned by: nothing the reference
-ships (it has no test or fixture for `generate`, and its module cannot be imported here: torch_xla / peft / omegaconf are
-absent) -- "parity unpinned"; the restatement is line-shaped so that it can be checked by reading it next to the reference.
+product (certifiedgpt_amd/minigpt4.py) embeds a shared prompt once and broadcasts it.  Pinned by:
+tests/golden/generate_golden.{json,npz}, produced by oracle/gen_golden_generate.py, which EXECUTES the reference's own
+`MiniGPTBase.generate` / `get_context_emb` (minigpt_base.py loaded by file path, unbound methods on a bare instance; CPU fp32, a
+random-init tiny Llama + the toy tokenizer, shared / ragged / single prompts, prescribed token rows and decoded strings for the
+clean-up lines): tests/test_minigpt4_cpu.py checks this restatement AND the product against it, answer by answer.
 """
 import torch
 

@@ -25,6 +25,7 @@ from gpu_util import DEV, make_classifier, rel_err
 
 pytestmark = pytest.mark.gpu
 
+TOL = 3e-3             # full-size fp16-GPU vs fp32-CPU activations / logits, relative to max|ref|: measured 2.5e-4 .. 8.8e-4
 MARGIN = 1e-2          # fp32 top-2 margin, relative to max|logit|, above which fp16 may not flip the vote
 K = 1000
 
@@ -77,7 +78,7 @@ def _check_certify(tag, gpu_out, ora_out, gpu_counts, ora_counts, gpu_logits, re
     err = rel_err(gpu_logits, ref_logits)
     print(f"[{tag}] argmax agreement {int(agree.sum())}/{len(agree)}, decisive {int(decisive.sum())}/{len(agree)}, "
           f"logits rel err {err:.2e}, gpu {gpu_out}, oracle {ora_out}")
-    assert err <= 2e-2, err
+    assert err <= TOL, err
     assert bool(agree[decisive].all()), (tag, "a decisive sample voted differently", int((~agree & decisive).sum()))
     flips = int(np.abs(gpu_counts - ora_counts).sum()) // 2
     assert flips <= int((~decisive).sum()), (tag, flips, int((~decisive).sum()))
@@ -142,6 +143,20 @@ def test_vitg_headline_sigma_argmax_agreement_and_radius(vitg_pair):
     assert rate >= 0.9
 
 
+def test_vitg_headline_certify_n100_sigma05_matches_cpu_oracle(vitg_pair):
+    """THE headline call (BASELINE configs[1]; smoothing.py:29-56): one whole `Smooth.certify(x, n0=100, n=100, alpha=0.001)` at
+    sigma = 0.5 on the GPU and on the CPU oracle with the same weights, image and noise draws.  200 fp32 ViT-G forwards on the host
+    (~100 s on 16 cores; a progress line per batch of 10).  Label / abstain equal and |dR| <= 1e-3 when the histograms agree; votes
+    may differ only on samples whose fp32 top-2 margin is below MARGIN."""
+    clf, cfg, params = vitg_pair
+    x = torch.from_numpy(mo.synthetic_image(cfg, seed=1235)).to(DEV)          # an image that certifies (profiles/r02/parity_headline.txt)
+    out = _certify_both(clf, cfg, params, x, 100, 100, 0.5, 0.001, 42)
+    rate = _check_certify("vitg headline n0=n=100 sigma=0.5", *out, 100, 0.001, 0.5)
+    assert rate >= 0.97
+    gpu_out, ora_out = out[0], out[1]
+    print(f"[vitg headline] abstain gpu {gpu_out[0] == cg.Smooth.ABSTAIN} oracle {ora_out[0] == so.ABSTAIN}, |dR| {abs(gpu_out[1] - ora_out[1]):.3e}")
+
+
 # ------------------------------------------------------------------ full-size encode_img (configs[2] minus the Vicuna decode)
 @pytest.fixture(scope="module")
 def encode_img_pair():
@@ -165,7 +180,7 @@ def test_full_size_encode_img_stages_match_oracle(encode_img_pair):
     errs = {w: rel_err(clf.activation(w, 2), ref[w]) for w in ("vit_out", "ln_vision", "qformer", "llama")}
     errs["logits"] = rel_err(logits, ref["logits"])
     print("[encode_img full size] rel err per stage:", {k: f"{v:.2e}" for k, v in errs.items()})
-    for w, tol in (("vit_out", 2e-2), ("ln_vision", 2e-2), ("qformer", 2e-2), ("llama", 2e-2), ("logits", 2e-2)):
+    for w, tol in (("vit_out", TOL), ("ln_vision", TOL), ("qformer", TOL), ("llama", TOL), ("logits", TOL)):
         assert errs[w] <= tol, (w, errs[w])
     assert ref["llama"].shape == (2, 32, 4096)
 
@@ -175,6 +190,84 @@ def test_full_size_encode_img_config0_certify_matches_cpu_oracle(encode_img_pair
     x = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
     out = _certify_both(clf, cfg, params, x, 10, 10, 0.25, 0.001, 42)
     _check_certify("encode_img config0", *out, 10, 0.001, 0.25)
+
+
+# ------------------------------------------------------------------ BASELINE configs[2] at its real dimensions
+def _vicuna_width_decoder(layers=2):
+    """A frozen fp16 decoder with Vicuna-7B's WIDTHS (hidden 4096, 32 heads, MLP 11008, vocabulary 32000; base_model.py:201-219 loads
+    the real one by local path) and `layers` random-init layers: the checkpoint is not in the container and nothing is downloaded."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    lcfg = LlamaConfig(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=layers, num_attention_heads=32,
+                       num_key_value_heads=32, max_position_embeddings=2048, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    torch.manual_seed(0)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float16)
+    try:
+        with torch.device(DEV):
+            llm = LlamaForCausalLM(lcfg).eval()
+    finally:
+        torch.set_default_dtype(prev)
+    for prm in llm.parameters():
+        prm.requires_grad = False
+    return llm
+
+
+def test_configs2_full_minigpt4_certify_n100_sigma05(encode_img_pair):
+    """BASELINE configs[2]: full MiniGPT-4 certify at N = 100, sigma = 0.5 with every hand-off at its real size -- full-size
+    `encode_img` (ViT-G + 12-layer Q-Former + llama_proj, [N,32,4096]) in HIP feeding a decoder with 4096-wide embeddings through
+    `MiniGPTBase.generate` (minigpt_base.py:374-448: prompt splice, 20 new tokens, greedy) on PyTorch-ROCm, answers -> labels -> HIP
+    vote.  `Smooth.certify(n0=100, n=100)` through the ENGINE path (noise fused into the patch-embed operand, prompt embedded once
+    and broadcast) against the REFERENCE-SHAPED path (`x.repeat + noise` batches of 100 -> encode_img -> one context embedding per
+    sample, left padding -> generate -> clean-up: oracle/generate_oracle.py, pinned by tests/golden/generate_golden.*), sample by
+    sample, and the certificate against the CPU statistics oracle."""
+    from certifiedgpt_amd.minigpt4 import MiniGPT4Classifier, WordHashTokenizer, prepare_texts
+    from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
+    from oracle import generate_oracle as go
+    enc, cfg, _ = encode_img_pair
+    assert (cfg.qf_queries, cfg.proj_dim) == (32, 4096)
+    llm = _vicuna_width_decoder()
+    tok = WordHashTokenizer(32000)
+    prompt = prepare_texts(["<Img><ImageHere></Img> [vqa] what is shown in the picture"])[0]
+    x = torch.from_numpy(mo.synthetic_image(cfg, seed=11)).to(DEV)
+    n0 = n = 100
+    sigma, alpha, seed, bs = 0.5, 0.001, 42, 100
+
+    # reference-shaped path (smoothing.py:91-98 around minigpt_base.py:374-448), batches of `bs` as `_sample_noise` cuts them
+    t0 = time.perf_counter()
+    ref_answers = []
+    for first in range(0, n0 + n, bs):
+        noisy = cg.noise_batch(x, first, bs, sigma, seed)                                  # x.repeat + randn * sigma
+        emb = torch.cat([enc.encode_img(noisy[i:i + enc.max_batch])[0] for i in range(0, bs, enc.max_batch)])
+        assert emb.shape == (bs, 32, 4096)
+        ref_answers += go.generate(llm, tok, emb.to(torch.float16), [prompt] * bs, max_new_tokens=20)
+    print(f"  reference-shaped path: {time.perf_counter() - t0:.1f} s, {len(set(ref_answers))} distinct answers of {len(ref_answers)}",
+          flush=True)
+    freq = sorted(set(ref_answers), key=lambda a: (-ref_answers.count(a), a))
+    vocab = freq[:9]
+    K2 = len(vocab) + 1
+    lab = [vocab.index(a) if a in vocab else K2 - 1 for a in ref_answers]
+    want_sel = np.bincount(lab[:n0], minlength=K2)
+    want_est = np.bincount(lab[n0:], minlength=K2)
+
+    # engine path
+    clf = MiniGPT4Classifier(enc, llm, tok, prompt, AnswerLabelMap(K2, vocab, frozen=True), max_new_tokens=20, max_batch=bs)
+    s = cg.Smooth(clf, K2, sigma, seed=seed, non_certifiable=(clf.label_map.other_id,))
+    t0 = time.perf_counter()
+    got_sel = s._sample_noise(x, n0, bs)
+    sel_answers = list(clf.last_answers)
+    got_est = s._sample_noise(x, n, bs)
+    print(f"  engine path: {time.perf_counter() - t0:.1f} s; counts sel {got_sel.tolist()} est {got_est.tolist()}", flush=True)
+    assert sel_answers == ref_answers[:n0] and clf.last_answers == ref_answers[n0:]        # sample by sample
+    assert got_sel.tolist() == want_sel.tolist() and got_est.tolist() == want_est.tolist()
+    s.reset()
+    got = s.certify(x, n0, n, alpha, bs)
+    want = so.certify_from_counts(want_sel, want_est, n, alpha, sigma)
+    if want[0] == clf.label_map.other_id:
+        want = (cg.Smooth.ABSTAIN, 0.0)
+    print(f"[configs2 full size] certify gpu {got} oracle-statistics {want}")
+    assert got[0] == want[0] and abs(got[1] - want[1]) <= 1e-9
+    del llm
+    torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------ ViT-G at the reference's own image size (448 x 448, T = 1025)
@@ -200,7 +293,7 @@ def test_vitg_448_streaming_attention_matches_cpu_oracle():
         e_log = rel_err(logits, ref["logits"])
         print(f"[vitg 448] rel err vit_out {e_vit:.2e} logits {e_log:.2e}")
         assert ref["vit_out"].shape == (1, 1025, 1408)
-        assert e_vit <= 2e-2 and e_log <= 2e-2, (e_vit, e_log)
+        assert e_vit <= TOL and e_log <= TOL, (e_vit, e_log)
         assert int(logits.argmax()) == int(ref["logits"].argmax()) or float(ref["logits"].topk(2).values.diff().abs()) <= MARGIN * float(ref["logits"].abs().max())
     finally:
         clf.close()

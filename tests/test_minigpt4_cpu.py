@@ -1,13 +1,93 @@
 """Host logic of the MiniGPT-4 `generate` base classifier (certifiedgpt_amd/minigpt4.py) on the CPU: prompt splice, left
-padding, greedy decode through a random-init tiny LlamaForCausalLM, decode clean-up, answer -> label -- against the
-statement-by-statement restatement of minigpt_base.py:75-89,374-448 in oracle/generate_oracle.py.  The encoder is a stub
+padding, greedy decode through a random-init tiny LlamaForCausalLM, decode clean-up, answer -> label -- against
+tests/golden/generate_golden.{json,npz}, which oracle/gen_golden_generate.py produced by EXECUTING the reference's own
+`MiniGPTBase.generate` / `get_context_emb` (minigpt_base.py:75-89,374-448) and `CONV_VISION_minigptv2` prompt template, and
+against the statement-by-statement restatement oracle/generate_oracle.py (itself pinned by the same fixture).  The encoder is a stub
 (encode_img needs the GPU); the GPU test tests/test_gpu_minigpt4.py runs the same classifier over cgpt_encode_img."""
+import json
+import os
+
+import numpy as np
+import pytest
 import torch
 
 from certifiedgpt_amd.minigpt4 import MiniGPT4Classifier, prepare_texts, clean_answer
 from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
 from oracle import generate_oracle as go
 from toy_llm import ToyTokenizer, StubEncoder, tiny_llama
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "generate_golden")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    meta = json.load(open(GOLD + ".json"))
+    arrays = np.load(GOLD + ".npz")
+    llm = tiny_llama(hidden=meta["llama"]["hidden"], seed=123)          # the seed is irrelevant: the fixture carries the weights
+    llm.load_state_dict({k[len("llama."):]: torch.from_numpy(arrays[k]) for k in arrays.files if k.startswith("llama.")})
+    return meta, arrays, llm.eval()
+
+
+def _gold_classifier(llm, max_new_tokens):
+    return MiniGPT4Classifier(StubEncoder(), llm, ToyTokenizer(), "<ImageHere>", AnswerLabelMap(4, ()), max_new_tokens=max_new_tokens)
+
+
+def test_reference_generate_goldens_pin_the_oracle_and_the_product(golden):
+    """Every case the reference's own MiniGPTBase.generate produced (shared, ragged and single prompts; 6 and 20 new tokens)."""
+    meta, arrays, llm = golden
+    n = 0
+    for case in meta["cases"]:
+        if "max_new_tokens" not in case:
+            continue
+        emb = torch.from_numpy(arrays[case["embeds"]])
+        assert prepare_texts(case["questions"]) == case["texts"]                       # conversation.py:130-137 by execution
+        got_oracle = go.generate(llm, ToyTokenizer(), emb, case["texts"], max_new_tokens=case["max_new_tokens"])
+        assert got_oracle == case["answers"], case["name"]
+        clf = _gold_classifier(llm, case["max_new_tokens"])
+        assert clf.generate_from_embeds(emb, case["texts"]) == case["answers"], case["name"]
+        if len(set(case["texts"])) == 1:
+            assert clf.generate_from_embeds(emb, case["texts"][0]) == case["answers"]  # ONE str shared by all rows
+        n += 1
+    assert n == 6
+
+
+def test_reference_context_embedding_goldens(golden):
+    meta, arrays, llm = golden
+    clf = _gold_classifier(llm, 6)
+    for name in ("shared", "ragged", "single"):
+        case = next(c for c in meta["cases"] if c["name"] == f"{name}_mnt6")
+        emb = torch.from_numpy(arrays[f"emb.{name}"])
+        want = torch.from_numpy(arrays[f"ctx.{name}"])
+        with torch.no_grad():
+            assert torch.equal(clf.get_context_emb(case["texts"][0], [emb[0][None]]), want)
+            assert torch.equal(go.get_context_emb(llm.get_input_embeddings(), ToyTokenizer(), case["texts"][0], [emb[0][None]]), want)
+
+
+def test_reference_decode_cleanup_goldens(golden):
+    """minigpt_base.py:441-447 driven by the reference on prescribed token rows and prescribed decoded strings."""
+    meta, arrays, llm = golden
+    rows = next(c for c in meta["cases"] if c["name"] == "scripted_cleanup")
+    strs = next(c for c in meta["cases"] if c["name"] == "scripted_strings")
+    assert [clean_answer(s) for s in strs["decoded"]] == strs["answers"]
+
+    class Scripted:
+        def __init__(self, inner, out):
+            self.inner, self.out = inner, out
+
+        def get_input_embeddings(self):
+            return self.inner.get_input_embeddings()
+
+        def parameters(self):
+            return self.inner.parameters()
+
+        def generate(self, **kw):
+            return torch.tensor(self.out, dtype=torch.long)
+
+    emb = torch.from_numpy(arrays["emb.scripted"])
+    clf = MiniGPT4Classifier(StubEncoder(), Scripted(llm, rows["rows"]), ToyTokenizer(), "<ImageHere>", AnswerLabelMap(4, ()))
+    assert clf.generate_from_embeds(emb, rows["texts"]) == rows["answers"]
+    assert go.generate(Scripted(llm, rows["rows"]), ToyTokenizer(), emb, rows["texts"]) == rows["answers"]
+
 
 PROMPT = prepare_texts(["<Img><ImageHere></Img> [vqa] what is shown here"])[0]
 
