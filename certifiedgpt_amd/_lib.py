@@ -56,6 +56,7 @@ SIGNATURES = {
     "cgpt_rgf_step": (_I32, [_P, _P, _I64, _I64, _I32, _P, _F, _F, _U64, _P, _P]),
     "cgpt_vote": (_I32, [_P, _I64, _I32, _P, _P]),
     "cgpt_allreduce_counts": (_I32, [_P, _P, _I64, _P]),
+    "cgpt_allreduce_counts_fn": (_I32, [_P, _P, _P, _I64, _P]),
     "cgpt_certify_from_counts": (_I32, [_P, _P, _I32, _I64, _D, _D, C.POINTER(_I32), C.POINTER(_D)]),
     "cgpt_predict_from_counts": (_I32, [_P, _I32, _D, C.POINTER(_I32)]),
     "cgpt_certify_device": (_I32, [_P, _P, _I32, _I64, _D, _D, _P, _P]),

@@ -3,7 +3,7 @@ r"""Text -> label adapter ("decoder-to-label" mapping, reference README.md:28-29
 A generated answer string is normalised and looked up in an answer vocabulary of at most `num_classes - 1` entries; the last
 class id is "other".  The normaliser reproduces the VQA accuracy normaliser the reference ships for scoring
 (common/vqa_tools/vqa_eval.py:211-216 answer clean-up, :249-259 punctuation, :261-274 number words / articles / contractions),
-including its quirks (the `(?!<=\d)` look-ahead typo, the reversed "somebody'd" entry, and the fact that its capitalised
+including its quirks (the `(?!<=\d)` look-ahead typo, the period strip that stops after 32 matches, the reversed "somebody'd" entry, and the fact that its capitalised
 contraction keys can never match a lower-cased word).  tests/golden/label_adapter_golden.json holds outputs of the reference's
 own normaliser -- every key of its contraction table among them -- which this one must reproduce.
 
@@ -57,7 +57,7 @@ def _process_punctuation(t: str) -> str:
             out = out.replace(p, "")
         else:
             out = out.replace(p, " ")
-    return _PERIOD.sub("", out)
+    return _PERIOD.sub("", out, count=32)        # the reference passes re.UNICODE (= 32) in the COUNT position, vqa_eval.py:257
 
 
 def normalize_answer(text: str) -> str:

@@ -157,7 +157,17 @@ def build_generating_classifier(encoder, gen_cfg, num_classes, tokenizer=None, l
     for p_ in llama_model.parameters():                      # frozen decoder, base_model.py:236-238
         p_.requires_grad = False
     prompt = gen_cfg.get("prompt") or prepare_texts(["<Img><ImageHere></Img> " + gen_cfg.get("question", "")])[0]
-    label_map = AnswerLabelMap(num_classes, gen_cfg.get("answers", ()), frozen=True)
+    answers = list(gen_cfg.get("answers", ()) or ())
+    from .label_adapter import normalize_answer
+    distinct = len({normalize_answer(a) for a in answers})
+    if distinct == 0:
+        raise ValueError("model.generate.answers is empty: every generated answer would map to the non-certifiable \"other\" class "
+                         "and every certify / predict call would return ABSTAIN")
+    if distinct > num_classes - 1:
+        raise ValueError(f"model.generate.answers has {distinct} distinct normalised answers but run.smoothing.num_classes = "
+                         f"{num_classes} leaves room for {num_classes - 1} (the last class id is \"other\"): raise num_classes "
+                         "or shorten the vocabulary -- truncating it would move real answers into the non-certifiable bucket")
+    label_map = AnswerLabelMap(num_classes, answers, frozen=True)
     return MiniGPT4Classifier(encoder, llama_model, tokenizer, prompt, label_map,
                               max_new_tokens=int(gen_cfg.get("max_new_tokens", 20)), max_batch=encoder.max_batch)
 

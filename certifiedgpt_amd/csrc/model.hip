@@ -10,6 +10,8 @@
 //              Row counts are padded to 256 and K-dims to 64 so every GEMM tile load is in bounds; pad columns
 //              are zero at allocation and never written.
 #include <dlfcn.h>
+#include <link.h>
+#include <string.h>
 #include <hip/hip_runtime.h>
 
 #include <map>
@@ -703,24 +705,48 @@ cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes,
 }
 
 // The one collective of the path: sum the int64 vote histograms of all ranks in place.  RCCL is not linked into
-// this library: ncclAllReduce is taken from the process when the caller (who created the communicator) has RCCL loaded, else from
-// librccl.so.  ncclInt64 = 4, ncclSum = 0 (rccl.h).
-cgpt_status cgpt_allreduce_counts(void* rccl_comm, int64_t* counts_dev, int64_t count, void* stream) {
-    if (!rccl_comm || !counts_dev || count < 1) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_allreduce_counts: bad argument");
-    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-    static allreduce_fn fn = nullptr;
-    if (!fn) {
-        fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
-        if (!fn) {
-            void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (lib) fn = (allreduce_fn)dlsym(lib, "ncclAllReduce");
-        }
-        if (!fn) return cgpt_fail(CGPT_ERR_STATE, "cgpt_allreduce_counts: ncclAllReduce not found (is RCCL installed?)");
+// this library.  A communicator is only valid inside the RCCL instance that created it, so ncclAllReduce is taken from a library
+// that is ALREADY MAPPED in the process and never from a freshly loaded one: the caller either hands the function over
+// (cgpt_allreduce_counts_fn) or exactly one librccl must be mapped, whatever its dlopen flags (torch's bundled copy is
+// RTLD_LOCAL: dlsym(RTLD_DEFAULT) does not see it, dl_iterate_phdr + dlopen(RTLD_NOLOAD) does).  Nothing is cached: no shared
+// state, any thread may call.  ncclInt64 = 4, ncclSum = 0 (rccl.h).
+typedef int (*cgpt_nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+
+static int collect_rccl(struct dl_phdr_info* info, size_t, void* data) {
+    const char* name = info->dlpi_name;
+    if (name && *name) {
+        const char* base = strrchr(name, '/');
+        base = base ? base + 1 : name;
+        if (strncmp(base, "librccl.so", 10) == 0) static_cast<std::vector<std::string>*>(data)->push_back(name);
     }
-    const int rc = fn(counts_dev, counts_dev, (size_t)count, /*ncclInt64*/ 4, /*ncclSum*/ 0, rccl_comm, (hipStream_t)stream);
+    return 0;
+}
+
+cgpt_status cgpt_allreduce_counts_fn(void* nccl_allreduce, void* rccl_comm, int64_t* counts_dev, int64_t count, void* stream) {
+    if (!nccl_allreduce || !rccl_comm || !counts_dev || count < 1)
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_allreduce_counts_fn: bad argument");
+    const int rc = ((cgpt_nccl_allreduce_fn)nccl_allreduce)(counts_dev, counts_dev, (size_t)count, /*ncclInt64*/ 4, /*ncclSum*/ 0,
+                                                            rccl_comm, (hipStream_t)stream);
     if (rc != 0) return cgpt_fail(CGPT_ERR_HIP, "cgpt_allreduce_counts: ncclAllReduce returned " + std::to_string(rc));
     return CGPT_OK;
+}
+
+cgpt_status cgpt_allreduce_counts(void* rccl_comm, int64_t* counts_dev, int64_t count, void* stream) {
+    if (!rccl_comm || !counts_dev || count < 1) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_allreduce_counts: bad argument");
+    std::vector<std::string> mapped;
+    dl_iterate_phdr(collect_rccl, &mapped);
+    if (mapped.empty())
+        return cgpt_fail(CGPT_ERR_STATE, "cgpt_allreduce_counts: no librccl is mapped in this process, so rccl_comm cannot be a live "
+                                         "communicator (create it with the RCCL you loaded, then call again)");
+    if (mapped.size() > 1)
+        return cgpt_fail(CGPT_ERR_STATE, "cgpt_allreduce_counts: " + std::to_string(mapped.size()) + " RCCL instances are mapped (" +
+                                         mapped[0] + ", " + mapped[1] + "): pass the ncclAllReduce of the one that created the "
+                                         "communicator to cgpt_allreduce_counts_fn");
+    void* lib = dlopen(mapped[0].c_str(), RTLD_NOLOAD | RTLD_NOW);          // a handle to the mapped instance; loads nothing
+    void* fn = lib ? dlsym(lib, "ncclAllReduce") : nullptr;
+    if (lib) dlclose(lib);                                                   // drops only the reference RTLD_NOLOAD took
+    if (!fn) return cgpt_fail(CGPT_ERR_STATE, "cgpt_allreduce_counts: " + mapped[0] + " is mapped but its ncclAllReduce cannot be reached");
+    return cgpt_allreduce_counts_fn(fn, rccl_comm, counts_dev, count, stream);
 }
 
 cgpt_status cgpt_certify_device(const int64_t* counts_selection_dev, const int64_t* counts_estimation_dev, int32_t num_classes,

@@ -179,8 +179,14 @@ cgpt_status cgpt_vote(const float* logits_dev, int64_t num, int32_t num_classes,
  *      on each rank's shard of the sample range -- ncclAllReduce(counts, counts, count, ncclInt64, ncclSum, comm, stream) over
  *      xGMI.  rccl_comm is the caller's ncclComm_t (one process per GPU); count = num_classes for one histogram, or
  *      num_images * 2 * num_classes for the table of cgpt_sample_counts_images.  Enqueued on `stream`, no host sync.
- *      (The reference has no call site: its collectives are torch_xla's) ---- */
+ *      (The reference has no call site: its collectives are torch_xla's)
+ *      SAME-INSTANCE REQUIREMENT: a communicator lives inside the RCCL library instance that created it.  libcgpt.so does not
+ *      link RCCL and never loads one: cgpt_allreduce_counts binds to the ONE librccl already mapped in the process (whatever its
+ *      dlopen flags) and returns CGPT_ERR_STATE when none or more than one is mapped (e.g. torch's bundled copy next to
+ *      /opt/rocm's); in that case, or whenever you hold the pointer anyway, pass the ncclAllReduce of the library that created
+ *      rccl_comm to cgpt_allreduce_counts_fn.  Stateless and callable from any thread. ---- */
 cgpt_status cgpt_allreduce_counts(void* rccl_comm, int64_t* counts_dev, int64_t count, void* stream);
+cgpt_status cgpt_allreduce_counts_fn(void* nccl_allreduce, void* rccl_comm, int64_t* counts_dev, int64_t count, void* stream);
 
 /* ---- statistics: pure host functions, float64, no device needed ----
  * Smooth.certify lines 46-56 given the two histograms (smoothing.py:44,48). */

@@ -24,6 +24,9 @@ ANSWERS = ["Yes", "no.", " A dog ", "the red car", "Two", "two dogs and a cat", 
 
 ANSWERS += ["I dont know", "its not there, isnt it", "thats what shes doing", "Im sure Ive seen it", "somebody'd say so",
             "theyre at 5 oclock", "yall come back", "he said: couldnt've", "whats that?", "don't", "it's"]
+# periodStrip.sub("", outText, re.UNICODE) (vqa_eval.py:257): the third positional argument is COUNT (= int(re.UNICODE) = 32), so only
+# the first 32 matching periods are stripped
+ANSWERS += ["a" + "." * 31 + "b", "a" + "." * 32 + "b", "a" + "." * 33 + "b", "x. " * 40 + "end.", "..." * 15 + " 3.5 " + ". ." * 10]
 ANSWERS += sorted(ev.contractions.keys())
 ANSWERS += ["the " + k + " thing" for k in sorted(ev.contractions.keys())[::7]]
 ANSWERS += sorted(set(ev.contractions.values()))

@@ -159,3 +159,24 @@ def test_certify_agent_scores_vqa_samples_by_answer_text(tmp_path):
     assert recs[1]["correct"] == 0.0
     res = agent.finalize()
     assert abs(res["accuracy"] - 0.3) < 1e-9 and abs(res["certified_acc@0.25"] - 0.3) < 1e-9
+
+
+def test_generating_classifier_rejects_an_empty_or_oversized_vocabulary():
+    """An empty vocabulary would make every call ABSTAIN silently; one longer than num_classes - 1 would be truncated silently."""
+    import pytest
+    from certifiedgpt_amd.agents.minigpt4_certify_agent import build_generating_classifier
+
+    class Enc:
+        max_batch = 4
+
+    class LM:
+        def parameters(self):
+            return iter(())
+
+    for answers, K, word in (((), 5, "empty"), (None, 5, "empty"), (["a cat", "dog", "the dog", "two", "2", "bus"], 4, "distinct")):
+        with pytest.raises(ValueError) as e:
+            build_generating_classifier(Enc(), {"prompt": "<ImageHere> q", "answers": answers}, K, tokenizer=object(), llama_model=LM())
+        assert word in str(e.value)
+    clf = build_generating_classifier(Enc(), {"prompt": "<ImageHere> q", "answers": ["a dog", "dog", "two", "2"]}, 3,
+                                      tokenizer=object(), llama_model=LM())          # 2 distinct normalised answers + other
+    assert clf.label_map.frozen and clf.label_map.answers == ["dog", "2"]

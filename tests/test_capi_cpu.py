@@ -165,3 +165,30 @@ def test_scalar_statistics_against_current_scipy_on_wide_ranges():
     assert worst_lcb <= 1e-9, worst_lcb
     assert worst_ppf <= 1e-12, worst_ppf
     assert worst_bt <= 1e-9, worst_bt
+
+
+def test_allreduce_counts_never_loads_an_rccl_of_its_own():
+    """cgpt_allreduce_counts binds only to an RCCL instance that is already mapped (a communicator lives inside the instance that
+    created it): none mapped -> CGPT_ERR_STATE, two mapped -> CGPT_ERR_STATE naming both; resolution only, no collective is
+    issued.  In a child process without torch (importing torch maps its bundled librccl)."""
+    import glob
+    import subprocess
+    import sys
+    libs = [p for p in ["/opt/rocm/lib/librccl.so"] + glob.glob("/usr/local/lib/python3*/dist-packages/torch/lib/librccl.so")
+            if os.path.exists(p)]
+    code = f"""
+import ctypes as C
+L = C.CDLL({_lib.LIB_PATH!r}); L.cgpt_last_error.restype = C.c_char_p
+L.cgpt_allreduce_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+def mapped(): return sorted({{l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l}})
+assert mapped() == []
+assert L.cgpt_allreduce_counts(C.c_void_p(1), C.c_void_p(8), 4, None) == 5 and b'no librccl is mapped' in L.cgpt_last_error()
+assert mapped() == []                                    # and it did not load one
+libs = {libs!r}
+if len(libs) >= 2:
+    keep = [C.CDLL(p) for p in libs[:2]]
+    assert L.cgpt_allreduce_counts(C.c_void_p(1), C.c_void_p(8), 4, None) == 5 and b'2 RCCL instances are mapped' in L.cgpt_last_error()
+print('ok')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr

@@ -149,7 +149,7 @@ def test_c_level_allreduce_counts_single_rank_communicator():
     rccl = None
     for path in cands:
         try:
-            rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)          # global: cgpt_allreduce_counts must use the SAME RCCL instance
+            rccl = C.CDLL(path)                              # RTLD_LOCAL, as torch maps its bundled copy: invisible to dlsym(RTLD_DEFAULT)
             break
         except OSError:
             continue
@@ -170,10 +170,22 @@ def test_c_level_allreduce_counts_single_rank_communicator():
         want = counts.clone()
         L = cg.lib()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = L.cgpt_allreduce_counts(comm, C.c_void_p(counts.data_ptr()), counts.numel(), st)
+        # explicit form: the ncclAllReduce of the instance that created the communicator
+        fn = C.cast(rccl.ncclAllReduce, C.c_void_p)
+        rc = L.cgpt_allreduce_counts_fn(fn, comm, C.c_void_p(counts.data_ptr()), counts.numel(), st)
         assert rc == 0, L.cgpt_last_error()
         torch.cuda.synchronize()
         assert torch.equal(counts, want)
+        # implicit form: binds to the ONE mapped librccl (same instance) or refuses when several are mapped -- never loads another
+        mapped = {os.path.realpath(l.split()[-1]) for l in open("/proc/self/maps") if "librccl.so" in l}
+        rc = L.cgpt_allreduce_counts(comm, C.c_void_p(counts.data_ptr()), counts.numel(), st)
+        if len(mapped) == 1:
+            assert rc == 0, L.cgpt_last_error()
+            torch.cuda.synchronize()
+            assert torch.equal(counts, want)
+        else:
+            assert rc == 5 and b"instances are mapped" in L.cgpt_last_error()
+        assert {os.path.realpath(l.split()[-1]) for l in open("/proc/self/maps") if "librccl.so" in l} == mapped
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
