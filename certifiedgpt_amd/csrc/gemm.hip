@@ -358,7 +358,6 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
     for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
     if (t + (int)gridDim.x < ntiles) { set_tile(t + gridDim.x); stage_load(c & 1, 0); }
 
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int m0 = etm * BM2 + wr * (BM2 / WM) + r15;      // lane owns rows m0 + i*16, columns n0 + j*16 .. +3
     const int n0 = etn * BN_ + wc * (BN_ / WN) + 4 * g;
     const bool full = (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2);
@@ -372,10 +371,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
         }
         if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n);
         if constexpr (EPI == EPI_F16 || EPI == EPI_F16_GELU) {
-            if constexpr (EPI == EPI_F16_GELU) {
-                v = gelu_erf4(v);
-            }
-            const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            if constexpr (EPI == EPI_F16_GELU) hv = gelu_h4(hv);
             *reinterpret_cast<f16x4*>(reinterpret_cast<half_t*>(p.out) + orow + n) = hv;
         } else {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow + n) = v;
@@ -653,39 +650,6 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                 gemm_epilogue_256<EPI, TM, 3>(p, accn, bias4, etm * BM2 + wr * (BM2 / WM) + r15, ecol0 + wc * 48 + 4 * g, full);
             }
             lds_stores = false;
-        } else if (!NARROW && EPI == EPI_F16_GELU && full && (p.ldo & 7) == 0 && (p.ablate & 8192)) {
-            // ALTERNATIVE GELU epilogue, kept for A/B runs (gemm_ablate bit 8192): no LDS round trip; pairs of column tiles are
-            // exchanged with v_permlane16_swap, which leaves a lane with 8 consecutive columns -> 16-byte stores, 64-byte
-            // segments per row.  With plain stores it was 1.5 % faster for fc1 than the LDS path below; with nontemporal stores
-            // the LDS path's full 128-byte lines win by 1.5 % (64-byte streamed segments: 31 % more HBM write traffic, PMC).
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            // this lane's first store address; the others are uniform steps away (16 rows per i2, 32 columns per jp)
-            half_t* dst0 = reinterpret_cast<half_t*>(p.out) + ((int64_t)etm * BM2 + wr * (BM2 / WM) + r15) * p.ldo + ecol0 +
-                           wc * (BN_ / WN) + (g & 1) * 16 + (g >> 1) * 8;
-            const int64_t step = 16 * p.ldo;
-#pragma unroll
-            for (int i2 = 0; i2 < TM; ++i2) {
-#pragma unroll
-                for (int jp = 0; jp < TN / 2; ++jp) {
-                    f32x4 va = acc[i2][2 * jp] + bias4[2 * jp], vb = acc[i2][2 * jp + 1] + bias4[2 * jp + 1];
-                    if constexpr (EPI == EPI_F16_GELU) {
-                        const f32x2 a0 = gelu_erf2(f32x2{va[0], va[1]}), a1 = gelu_erf2(f32x2{va[2], va[3]});
-                        const f32x2 b0 = gelu_erf2(f32x2{vb[0], vb[1]}), b1 = gelu_erf2(f32x2{vb[2], vb[3]});
-                        va = f32x4{a0[0], a0[1], a1[0], a1[1]};
-                        vb = f32x4{b0[0], b0[1], b1[0], b1[1]};
-                    }
-                    const f16x4 ha = {(half_t)va[0], (half_t)va[1], (half_t)va[2], (half_t)va[3]};
-                    const f16x4 hb = {(half_t)vb[0], (half_t)vb[1], (half_t)vb[2], (half_t)vb[3]};
-                    const u32x2 ua = __builtin_bit_cast(u32x2, ha), ub = __builtin_bit_cast(u32x2, hb);
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                    const u32x4 packed = {s0[0], s1[0], s0[1], s1[1]};
-                    CGPT_STORE16(packed, reinterpret_cast<u32x4*>(dst0 + i2 * step + jp * 32));
-                }
-            }
-            lds_stores = early;
         } else if (F16_OUT && full && (p.ldo & 7) == 0 && !(p.ablate & 512)) {
             // fp16 output of a full tile: transposed through LDS so that a lane stores 16 contiguous bytes and 8 lanes one
             // 128-byte line.  (Straight from the accumulators a store instruction writes 16 rows x 32 bytes: 4x the L2 write
@@ -695,8 +659,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
             // Each wave owns 8 KiB of it and handles its 128 x 64 sub-tile in two passes of 64 rows; rows are 128 B, the
             // 16-byte chunk index is XOR-swizzled with row & 7 (conflict-free ds_write_b64 / ds_read_b128).  A 192-column tile
             // uses 6 of a row's 8 chunks (128 x 48 per wave): the read / store instructions run with 48 of 64 lanes.
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-            half_t* scr = smem3 + ((c + 1) & 1) * STAGE + wave * 4096;
+                    half_t* scr = smem3 + ((c + 1) & 1) * STAGE + wave * 4096;
             half_t* outp = reinterpret_cast<half_t*>(p.out);
             // lane coordinates recomputed here (volatile: not merged with the copies the K loop uses), so that no epilogue-only
             // value is kept -- or spilled -- across the K loop (a scratch reload would wait behind the LDS-DMA requests in flight)
@@ -715,11 +678,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
                     const int row = ii * 16 + r15;
 #pragma unroll
                     for (int jj = 0; jj < TNv; ++jj) {
-                        f32x4 v = acc[i][jj] + bias4[jj];
-                        if constexpr (EPI == EPI_F16_GELU) {
-                            v = gelu_erf4(v);
-                        }
-                        const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        const f32x4 v = acc[i][jj] + bias4[jj];
+                        f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        if constexpr (EPI == EPI_F16_GELU) hv = gelu_h4(hv);
                         const int ch = (jj * 2 + (g >> 1)) ^ (row & 7);
                         *reinterpret_cast<f16x4*>(scr + row * 64 + ch * 8 + (g & 1) * 4) = hv;
                     }
@@ -790,360 +751,7 @@ hipError_t launch_v3_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
 
 
 #ifdef CGPT_LAB   // lab-only schedules (slower or equal; kept for A/B runs: make LAB=1)
-// ------------------------------------------------------------------------------------------------ v4
-// 256x256 tile, K-steps of 32 in an NS-deep ring of 32-KiB LDS stages (NS = 4: 128 KiB), LDS-DMA requests running
-// D = NS-1 sub-tiles ahead behind a COUNTED s_waitcnt vmcnt (never 0 in steady state), phase-alternating halves as v3.
-// Why: with two 64-KiB stages a request has ~0.8 us to land, but under streaming load an LDS-DMA piece takes ~1.1 us
-// issue->landed (MI355X guide, ldsdma-fill); removing the in-loop loads from v3 took the fc2 GEMM from 861 to 659 us.
-//   LDS image of a stage: A [256 rows][32 halfs] then W [256][32]; a row is 64 B, so a 256-B bank row holds 4 tile rows.
-//   16-byte chunk c of row r sits at position c ^ ((-(r >> 2)) & 3): with it the 16 rows x one chunk of a fragment read
-//   hit 16 distinct 16-B slots for each of gfx950's ds_read_b128 lane groups (which mix chunk g and g+1).
-//   One LDS-DMA piece = 1 KiB = 16 rows x 64 B; lane l -> row l>>2, position l&3, source chunk (l&3) ^ ((-(l>>4)) & 3).
-//   Wave w requests A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of every sub-tile (4 requests per sub-tile per wave).
-// Per sub-tile s (32 MFMAs per wave):  L(s): 12 fragment reads, 4 requests for sub-tile s+D, lgkmcnt(0) | barrier |
-// M(s): 32 MFMAs | barrier; waves 4-7 run one slot behind waves 0-3.  Before the barrier that ends the slot in which the
-// early half computes M(s), every wave has retired its own requests for sub-tile s+1 (counted vmcnt leaves the D-1 younger
-// groups in flight), so after that barrier sub-tile s+1 is visible to everybody.  A stage is re-requested D-NS = -1 sub-tile
-// ... i.e. the stage of sub-tile s+D last held sub-tile s-1, whose reads both halves retired (lgkmcnt(0) before a barrier)
-// at least one full slot earlier.
-template <int EPI, int NS>
-__global__ __launch_bounds__(512, 2) void gemm4_f16_kernel(GemmParams p) {
-    constexpr int BM2 = 256, BN_ = 256, WN = 4, WM = 2, BK4 = 32;
-    constexpr int TM = 8, TN = 4;
-    constexpr int A_ELEMS = BM2 * BK4, STAGE = (BM2 + BN_) * BK4;     // halfs
-    constexpr int D = NS - 1;
-    extern __shared__ __attribute__((aligned(16))) half_t smem4[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WN, wc = wave % WN;
-    const bool late = wave >= 4;
-    const int r15 = lane & 15, g = lane >> 4;
-
-    const int tiles_m = (p.M + BM2 - 1) / BM2;
-    const int tiles_n = (p.N + BN_ - 1) / BN_;
-    const int ntiles = tiles_m * tiles_n;
-
-    // LDS-DMA sources: piece pc (0,1) of this wave covers tile rows (2*wave + pc)*16 + (lane>>2)
-    const int prow = lane >> 2;
-    const int psrc = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) << 3;          // source chunk (halfs) for this lane
-    const half_t* a_src[2];
-    const half_t* b_src[2];
-    int tm = 0, tn = 0;
-    auto set_tile = [&](int t) {
-        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn);
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-            const int r = (2 * wave + pc) * 16 + prow;
-            a_src[pc] = p.A + (int64_t)(tm * BM2 + r) * p.lda + psrc;
-            b_src[pc] = p.W + (int64_t)(tn * BN_ + r) * p.ldw + psrc;
-        }
-    };
-    auto request = [&](int stage, int s) {                                  // 4 LDS-DMA pieces of sub-tile s
-        half_t* sa = smem4 + stage * STAGE + (2 * wave) * 16 * BK4;
-        half_t* sb = sa + A_ELEMS;
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[pc] + s * BK4),
-                                             (__attribute__((address_space(3))) void*)(sa + pc * 16 * BK4), 16, 0, 0);
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[pc] + s * BK4),
-                                             (__attribute__((address_space(3))) void*)(sb + pc * 16 * BK4), 16, 0, 0);
-    };
-
-    const int rsw = ((g ^ ((0 - (r15 >> 2)) & 3)) << 3);                    // swizzled chunk offset of this lane's fragment
-    const int a_rd = (wr * (BM2 / WM) + r15) * BK4 + rsw;
-    const int b_rd = A_ELEMS + (wc * (BN_ / WN) + r15) * BK4 + rsw;
-
-    f32x4 acc[TM][TN];
-    f16x8 af[TM], bf[TN];
-#define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
-#define CGPT_SLOT_END CGPT_FENCE __builtin_amdgcn_s_barrier(); CGPT_FENCE
-    // retire this wave's requests for the sub-tile that is `younger` groups behind the newest one (4 requests per group)
-#define CGPT_RETIRE(younger)                                                       \
-    do {                                                                           \
-        if ((younger) >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      \
-        else if ((younger) == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  \
-        else if ((younger) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
-    } while (0)
-
-    const int ns = p.K / BK4;
-    int c = 0;                                     // running sub-tile counter: sub-tile lives in stage c % NS
-    int t = blockIdx.x;
-    if (t < ntiles) {
-        set_tile(t);
-        for (int s = 0; s < D && s < ns; ++s) request(s % NS, s);
-    }
-    for (; t < ntiles; t += gridDim.x) {
-        f32x4 bias4[TN];
-        {
-            const int nb0 = tn * BN_ + wc * (BN_ / WN) + 4 * g;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias && nb0 + j * 16 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + j * 16);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // sub-tile 0 (requested before the previous epilogue / at kernel start) must be visible: the previous tile's
-        // stores and the bias loads are younger than those requests, so only vmcnt(0) is exact here.
-        __syncthreads();
-        if (late) { CGPT_SLOT_END }
-
-        for (int s = 0; s < ns; ++s, ++c) {
-            const half_t* st = smem4 + (c % NS) * STAGE;
-            // ---------------- L(s)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK4);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 16 * BK4);
-            if (s + D < ns && !(p.ablate & 1)) request((c + D) % NS, s + D);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // groups younger than the one of sub-tile s+1: sub-tiles s+2 .. min(s+D, ns-1)
-            const int younger = (s + D < ns ? s + D : ns - 1) - (s + 1);
-            if (late && s + 1 < ns) CGPT_RETIRE(younger);
-            CGPT_SLOT_END
-            // ---------------- M(s): 32 MFMAs
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-            if (!late && s + 1 < ns) CGPT_RETIRE(younger);
-            CGPT_SLOT_END
-        }
-        if (!late) { CGPT_SLOT_END }
-
-        const int etm = tm, etn = tn;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
-        if (t + (int)gridDim.x < ntiles) {
-            set_tile(t + gridDim.x);
-            for (int s = 0; s < D && s < ns; ++s) request((c + s) % NS, s);
-        }
-        gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g,
-                                      (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2));
-    }
-#undef CGPT_FENCE
-#undef CGPT_SLOT_END
-#undef CGPT_RETIRE
-}
-
-template <int EPI, int NS>
-hipError_t launch_v4(const GemmParams& p, hipStream_t stream) {
-    constexpr int lds_bytes = NS * (256 + 256) * 32 * (int)sizeof(half_t);
-    DeviceInfo di;
-    if (hipError_t e = device_info(di); e != hipSuccess) return e;
-    static bool configured[kMaxDevices] = {false};
-    if (hipError_t e = configure_lds(&gemm4_f16_kernel<EPI, NS>, lds_bytes, configured, di.dev); e != hipSuccess) return e;
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const int num_cus = di.num_cus;
-    const int grid = tiles < num_cus ? tiles : num_cus;
-    hipLaunchKernelGGL((gemm4_f16_kernel<EPI, NS>), dim3(grid), dim3(512), lds_bytes, stream, p);
-    return hipGetLastError();
-}
-
-template <int NS>
-hipError_t launch_v4_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
-    switch (epilogue) {
-        case EPI_F16: return launch_v4<EPI_F16, NS>(p, stream);
-        case EPI_F16_GELU: return launch_v4<EPI_F16_GELU, NS>(p, stream);
-        case EPI_F32: return launch_v4<EPI_F32, NS>(p, stream);
-        case EPI_RESID: return launch_v4<EPI_RESID, NS>(p, stream);
-        case EPI_PATCH: return launch_v4<EPI_PATCH, NS>(p, stream);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-// v5 = v3 (4 phases) with the fragment reads running ONE PHASE AHEAD of the MFMAs that consume them (double-buffered A and
-// W fragments), so that no L segment ends on an exposed LDS round trip: measured on v3, an L segment (reads + ~200-cycle LDS
-// latency + 4 LDS-DMA issues) takes ~400 cycles against the 256 cycles of the partner's 16 MFMAs.
-//   L0: read A(q0)->A0, W(k0)->W0 | 3 DMA pieces | read A(q1)->A1 | lgkmcnt(4)  (A0, W0 landed; they had the DMA issue time)
-//   L1: read A(q2)->A0, W(k1)->W1 | 3 DMA pieces | lgkmcnt(8)                   (A1 landed)
-//   L2: read A(q3)->A1            | 2 DMA pieces | lgkmcnt(4)                   (A0, W1 landed)
-//   L3:                                            lgkmcnt(0)                   (A1 landed)
-// The reads of a stage end in L2, two phases before the K-tile boundary; the stage is re-requested one K-tile later.
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm5_f16_kernel(GemmParams p) {
-    // 4 phases per K-tile
-    constexpr int BM2 = 256, BN_ = 256, WN = 4, WM = 2;
-    constexpr int TM = 8, TN = 4, HM = 4;
-    constexpr int A_ELEMS = BM2 * BK, B_ELEMS = BN_ * BK, STAGE = A_ELEMS + B_ELEMS;
-    constexpr int A_INSTR = 4, B_INSTR = 4;
-    extern __shared__ __attribute__((aligned(16))) half_t smem5[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WN, wc = wave % WN;
-    const bool late = wave >= 4;                       // the half that runs one slot behind
-    const int r15 = lane & 15, g = lane >> 4;
-
-    const int tiles_m = (p.M + BM2 - 1) / BM2;
-    const int tiles_n = (p.N + BN_ - 1) / BN_;
-    const int ntiles = tiles_m * tiles_n;
-
-    const int lr = lane >> 3, cpos = lane & 7;
-    const half_t* a_src[A_INSTR];
-    const half_t* b_src[B_INSTR];
-    int tm = 0, tn = 0;
-    auto set_tile = [&](int t) {
-        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn);
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            const int r = wave * (BM2 / 8) + i * 8 + lr;
-            a_src[i] = p.A + (int64_t)(tm * BM2 + r) * p.lda + ((cpos ^ ((r >> 1) & 7)) << 3);
-        }
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const int r = wave * (BN_ / 8) + i * 8 + lr;
-            b_src[i] = p.W + (int64_t)(tn * BN_ + r) * p.ldw + ((cpos ^ ((r >> 1) & 7)) << 3);
-        }
-    };
-    // LDS-DMA piece i of this wave (0-3: A rows, 4-7: W rows) of K-tile kt into `stage`
-    auto request_piece = [&](int stage, int kt, int i) {
-        if (i < 4) {
-            half_t* sa = smem5 + stage * STAGE + wave * (BM2 / 8) * BK + i * 8 * BK;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)sa, 16, 0, 0);
-        } else {
-            half_t* sb = smem5 + stage * STAGE + A_ELEMS + wave * (BN_ / 8) * BK + (i - 4) * 8 * BK;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i - 4] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)sb, 16, 0, 0);
-        }
-    };
-    auto request_all = [&](int stage, int kt) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) request_piece(stage, kt, i);
-    };
-    const int sw = (r15 >> 1) & 7;
-    const int k_off0 = ((g ^ sw) << 3), k_off1 = (((4 + g) ^ sw) << 3);
-    const int a_rd = (wr * (BM2 / WM) + r15) * BK;
-    const int b_rd = A_ELEMS + (wc * (BN_ / WN) + r15) * BK;
-
-    f32x4 acc[TM][TN];
-    f16x8 fa0[HM], fa1[HM], fw0[TN], fw1[TN];
-#define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
-#define CGPT_SLOT_END CGPT_FENCE __builtin_amdgcn_s_barrier(); CGPT_FENCE
-
-    const int nk = p.K / BK;
-    int c = 0;
-    int t = blockIdx.x;
-    if (t < ntiles) { set_tile(t); request_all(0, 0); }
-    for (; t < ntiles; t += gridDim.x) {
-        f32x4 bias4[TN];
-        {
-            const int nb0 = tn * BN_ + wc * (BN_ / WN) + 4 * g;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias && nb0 + j * 16 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + nb0 + j * 16);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();                               // K-tile 0 of this tile has landed; both halves aligned
-        if (late) { CGPT_SLOT_END }                    // the late half enters one slot behind
-
-        for (int kt = 0; kt < nk; ++kt, ++c) {
-            const half_t* st = smem5 + (c & 1) * STAGE;
-            const bool more = kt + 1 < nk;
-            const bool req = more && !(p.ablate & 1);
-            const int nxs = (c + 1) & 1;
-#define CGPT_RD_A(dst, h_, ko_)                                                                              \
-    _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                            \
-        dst[i] = *reinterpret_cast<const f16x8*>(st + a_rd + ((h_) * HM + i) * 16 * BK + (ko_));
-#define CGPT_RD_W(dst, ko_)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + (ko_));
-#define CGPT_MMQ(fa_, fw_, h_)                                                                                \
-    _Pragma("unroll") for (int i = 0; i < HM; ++i)                                                            \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                        \
-            acc[(h_) * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw_[j], fa_[i], acc[(h_) * HM + i][j], 0, 0, 0);
-            // ---- L0
-            CGPT_RD_A(fa0, 0, k_off0)
-            CGPT_RD_W(fw0, k_off0)
-            CGPT_FENCE
-            if (req) { request_piece(nxs, kt + 1, 0); request_piece(nxs, kt + 1, 1); request_piece(nxs, kt + 1, 2); }
-            CGPT_FENCE
-            CGPT_RD_A(fa1, 1, k_off0)
-            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-            CGPT_SLOT_END
-            CGPT_MMQ(fa0, fw0, 0)                     // M0: (k0, h0)
-            CGPT_SLOT_END
-            // ---- L1
-            CGPT_RD_A(fa0, 1, k_off1)
-            CGPT_RD_W(fw1, k_off1)
-            CGPT_FENCE
-            if (req) { request_piece(nxs, kt + 1, 3); request_piece(nxs, kt + 1, 4); request_piece(nxs, kt + 1, 5); }
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            CGPT_SLOT_END
-            CGPT_MMQ(fa1, fw0, 1)                     // M1: (k0, h1)
-            CGPT_SLOT_END
-            // ---- L2
-            CGPT_RD_A(fa1, 0, k_off1)
-            CGPT_FENCE
-            if (req) { request_piece(nxs, kt + 1, 6); request_piece(nxs, kt + 1, 7); }
-            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-            CGPT_SLOT_END
-            CGPT_MMQ(fa0, fw1, 1)                     // M2: (k1, h1)
-            CGPT_SLOT_END
-            // ---- L3
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            CGPT_SLOT_END
-            CGPT_MMQ(fa1, fw1, 0)                     // M3: (k1, h0)
-            if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            CGPT_SLOT_END
-#undef CGPT_RD_A
-#undef CGPT_RD_W
-#undef CGPT_MMQ
-        }
-        if (!late) { CGPT_SLOT_END }                   // the early half waits one slot for its partners' last M
-
-        const int etm = tm, etn = tn;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias4[j]));
-        if (t + (int)gridDim.x < ntiles) { set_tile(t + gridDim.x); request_all(c & 1, 0); }
-        gemm_epilogue_256<EPI, TM, TN>(p, acc, bias4, etm * BM2 + wr * (BM2 / WM) + r15, etn * BN_ + wc * (BN_ / WN) + 4 * g,
-                                      (etm + 1) * BM2 <= p.M && (etn + 1) * BN_ <= p.N && !(p.ablate & 2));
-    }
-#undef CGPT_FENCE
-#undef CGPT_SLOT_END
-}
-
-template <int EPI>
-hipError_t launch_v5(const GemmParams& p, hipStream_t stream) {
-    constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t);
-    DeviceInfo di;
-    if (hipError_t e = device_info(di); e != hipSuccess) return e;
-    static bool configured[kMaxDevices] = {false};
-    if (hipError_t e = configure_lds(&gemm5_f16_kernel<EPI>, lds_bytes, configured, di.dev); e != hipSuccess) return e;
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const int num_cus = di.num_cus;
-    const int grid = tiles < num_cus ? tiles : num_cus;
-    hipLaunchKernelGGL((gemm5_f16_kernel<EPI>), dim3(grid), dim3(512), lds_bytes, stream, p);
-    return hipGetLastError();
-}
-
-hipError_t launch_v5_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
-    switch (epilogue) {
-        case EPI_F16: return launch_v5<EPI_F16>(p, stream);
-        case EPI_F16_GELU: return launch_v5<EPI_F16_GELU>(p, stream);
-        case EPI_F32: return launch_v5<EPI_F32>(p, stream);
-        case EPI_RESID: return launch_v5<EPI_RESID>(p, stream);
-        case EPI_PATCH: return launch_v5<EPI_PATCH>(p, stream);
-        default: return hipErrorInvalidValue;
-    }
-}
-
+#include "lab/gemm_v4v5.inc"
 #endif  // CGPT_LAB
 
 }  // namespace
@@ -1153,9 +761,11 @@ int g_gemm_ablate = 0;
 int g_gemm_group_m = 4;   // measured: 4 ~ 8 > 2 > 16 (profiles/r01/gemm_variants.txt)
 unsigned long long* g_gemm_dbg = nullptr;
 
-// Result-preserving switches of gemm_ablate (each turns one optimisation off; outputs are bit-identical): the only bits a
-// production build honours.  Bits 1 / 2 / 4 (skip loads / stores / MFMAs: WRONG results, timing studies) exist in lab builds only.
-[[maybe_unused]] constexpr int kAblateSafeBits = 16 | 512 | 1024 | 8192 | 16384;
+// Result-preserving switches of gemm_ablate (TEST-ONLY: each turns one optimisation off so that a test can check the bits do not
+// depend on it): 512 = LDS-transposed fp16 epilogue, 16384 = 192-column last tiles for N = 256k + 128, 32768 = deferred GELU (gemm9.hip).
+// Lab builds additionally honour 16 / 1024 (request / wait placement of the phased kernel) and the WRONG-result timing switches
+// 1 / 2 / 4 (skip loads / stores / MFMAs).
+[[maybe_unused]] constexpr int kAblateSafeBits = 512 | 16384 | 32768;
 
 hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
@@ -1176,7 +786,7 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     const int force = vec_ok ? g_gemm_kernel : 1;   // 0 auto, 1 = 128x128 register-staged, 3 = 256x128 direct-to-LDS, 4 = 256x256 phased
     if (force == 3 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
     if (force == 4) return launch_v3_epi<4>(epilogue, p, stream);
-    if (force == 14) return launch_v9_epi(epilogue, p, stream, true);
+    if (force == 14 && v9_fits(p)) return launch_v9_epi(epilogue, p, stream);
 #ifdef CGPT_LAB
     if (force == 2) return launch_v2_epi<256>(epilogue, p, stream);
     if (force == 5) return launch_v3_epi<2>(epilogue, p, stream);
@@ -1186,9 +796,8 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     if (force == 9) return launch_v6_epi(epilogue, 0, p, stream);
     if (force == 10) return launch_v6_epi(epilogue, 1, p, stream);
     if (force == 11) return launch_v8_epi(epilogue, p, stream);
-    if (force == 12) return launch_v9_epi(epilogue, p, stream, false);
 #endif
-    if ((force == 0 || force == 13 || force == 15) && p.M >= 1024) {
+    if ((force == 0 || force == 15) && p.M >= 1024) {
         // measured on MI355X (profiles/r01/gemm_variants.txt): the 256x256 direct-to-LDS tile with the phase-alternating
         // schedule wins on every ViT / Q-Former shape, also when N is not a multiple of 256 (weights are allocated with 256-row
         // padding) ... except when 256x256 tiles would leave more than half of the 256 CUs idle (the Q-Former's N = 768 linears
@@ -1196,12 +805,12 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
         const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         if (tiles256 <= 128 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
 #ifdef CGPT_LAB
-        if (force == 13) return launch_v9_epi(epilogue, p, stream, false);   // lab: v9 wherever the automatic choice is v3
-        if (force == 15) return launch_v9_epi(epilogue, p, stream, true);    // lab: the two-phase quadrant kernel likewise
+        if (force == 15 && v9_fits(p)) return launch_v9_epi(epilogue, p, stream);          // lab: the two-phase quadrant kernel wherever the automatic choice is a 256x256 tile
 #endif
         // the two-phase quadrant kernel (gemm9.hip) wins on every ViT shape in the model: qkv 650 -> 611, proj 238 -> 229,
         // fc1 + GELU ~1 000 -> 976, fc2 859 -> 823 us per 255-sample launch (profiles/r02/gemm_two_phase_variants.txt)
-        return launch_v9_epi(epilogue, p, stream, true);
+        if (v9_fits(p)) return launch_v9_epi(epilogue, p, stream);
+        return launch_v3_epi<4>(epilogue, p, stream);                          // operands of 4 GiB or more: 64-bit addressing
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

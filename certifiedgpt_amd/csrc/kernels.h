@@ -28,20 +28,21 @@ struct GemmParams {
     int patches;                  // EPI_PATCH: P (patches per image)
     unsigned long long* dbg = nullptr;   // diagnostic builds only (-DCGPT_STAMPS): per-wave cycle sums
     int group_m = 8;              // tile-rows per group in the block->tile map (speed only)
-    int ablate = 0;               // measurement only: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs
+    int ablate = 0;               // lab builds: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs; tests: see launch_gemm
+    int defer_gelu = 0;           // set by the gemm9 launcher: EPI_F16_GELU finished inside the next tile's K loop
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
-// gemm9.hip: quadrant phases with a 1.5-K-tile LDS-DMA run-ahead; two_phase = the product form (32 MFMAs per phase), used for
-// long-K shapes; the four-phase form exists in lab builds only
-hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream, bool two_phase);
+// gemm9.hip: 256x256 tile, two 32-MFMA phases per K-tile, operand parts requested 1.5 K-tiles ahead by LDS-DMA
+hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream);
+bool v9_fits(const GemmParams& p);   // its 32-bit buffer offsets cover the operands
 #ifdef CGPT_LAB
-hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);   // gemm6.hip: 4-wave 128x128 wave tiles
-hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // gemm8.hip: two 4-wave workgroups per CU, 128x256 tiles
+hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);   // lab/gemm6.hip: 4-wave 128x128 wave tiles
+hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // lab/gemm8.hip: two 4-wave workgroups per CU, 128x256 tiles
 #endif
 extern int g_gemm_ablate;
 extern int g_gemm_group_m;
 extern unsigned long long* g_gemm_dbg;
-extern int g_gemm_kernel;   // kernel override (speed only): 0 auto, 1 = 128x128, 3 = 256x128, 4 = 256x256 phased, 14 = 256x256 two-phase quadrant; lab builds: 2, 5..13, 15
+extern int g_gemm_kernel;   // kernel override (speed only): 0 auto, 1 = 128x128, 3 = 256x128, 4 = 256x256 phased, 14 = 256x256 two-phase quadrant; lab builds: 2, 5..11, 15
 
 // ---------------------------------------------------------------------------------------- attention
 // O[b,q,h*hd + d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d]   (eva_vit.py:133-150,
