@@ -762,10 +762,10 @@ int g_gemm_group_m = 4;   // measured: 4 ~ 8 > 2 > 16 (profiles/r01/gemm_variant
 unsigned long long* g_gemm_dbg = nullptr;
 
 // Result-preserving switches of gemm_ablate (TEST-ONLY: each turns one optimisation off so that a test can check the bits do not
-// depend on it): 512 = LDS-transposed fp16 epilogue, 16384 = 192-column last tiles for N = 256k + 128, 32768 = deferred GELU (gemm9.hip).
+// depend on it): 512 = LDS-transposed fp16 epilogue, 16384 = 192-column last tiles for N = 256k + 128.
 // Lab builds additionally honour 16 / 1024 (request / wait placement of the phased kernel) and the WRONG-result timing switches
 // 1 / 2 / 4 (skip loads / stores / MFMAs).
-[[maybe_unused]] constexpr int kAblateSafeBits = 512 | 16384 | 32768;
+[[maybe_unused]] constexpr int kAblateSafeBits = 512 | 16384;
 
 hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;

@@ -22,29 +22,11 @@
 // tile, K-tile and part, instead of eight 64-bit per-lane pointers.  The first K-tile of a tile multiplies into a ZERO accumulator
 // operand instead of clearing 128 registers.
 //
-// Deferred GELU (EPI_F16_GELU, nn.GELU after Mlp.fc1, eva_vit.py:59-61).  128 outputs per lane and tile cost the two waves of a SIMD
-// ~7 k cycles of VALU issue with the matrix pipe idle (in-kernel stamps, profiles/r02/gemm_stamps.txt: epilogue 10 us of a 55-us tile
-// against 2.8-3.6 us for a plain one), and neither registers (247 of 256) nor LDS (160 of 160 KiB) can hold a tile's outputs across
-// the next tile.  So a full tile that has a successor writes h = fp16(acc + bias) -- the tensor the reference materialises between
-// `fc1` and `act` under autocast -- with the plain epilogue, and during K-tiles 1..17 of the successor each wave brings its 128 x 64
-// block back in 16 pieces of 1 KiB (8 rows; 16 bytes per lane, the lane's own bytes of the epilogue's stores) by LDS-DMA into its idle
-// epilogue scratch (L2 / Infinity-Cache hits, `sc1`: not through L1), reads a piece back in two halves, applies GELU to a half inside
-// an M segment -- where the VALU is otherwise idle -- and stores the piece (nontemporal).  Piece k is requested in L(P0) of K-tile
-// c = k + 1, retired by the counted wait that ends L(P1) of c, its first half computed in M(P1) of c, its second in M(P0) of c + 1, and
-// stored in L(P1) of c + 1; two 1-KiB slots alternate.  Loads, stores and LDS-DMA retire in issue order, so the counted waits grow by
-// exactly the deferred operations younger than what they wait for (derivation at `ktile`):
-//     K-tile    kind      L(P0) requests a piece    L(P1) stores a piece    vmcnt at the end of L(P0), L(P1)
-//     0         ZEROC              -                         -                       8, 8      (also every K-tile of a tile with
-//     1         FIRST              x                         -                       9, 8       nothing pending)
-//     2         SECOND             x                         x                       9, 9
-//     3..16     STEADY             x                         x                      10, 9
-//     17        LAST               -                         x                       9, 9
-//     18        AFTER              -                         -                       9, 8
-//     19..      NONE               -                         -                       8, 8
-// A smaller count than the exact one is always safe (it waits for more), a larger one never.  The last tile of a workgroup, a partial
-// tile, a 192-column tile and any launch with fewer than 18 K-tiles or N % 256 != 0 apply GELU in the epilogue as before; both forms
-// evaluate the same arithmetic on the fp16-rounded h (gelu_h4), so an element's value does not depend on the path its tile takes
-// (tested bitwise against the fused form: gemm_ablate bit 32768).
+// Tried and removed in round 3 (profiles/r03/gemm_deferred_gelu.txt): finishing fc1's GELU inside the NEXT tile's K loop -- raw fp16 tile
+// written by a plain epilogue, re-read in 1-KiB pieces by LDS-DMA into the idle epilogue scratch behind exactly re-counted waits, GELU in
+// the M segments, stored back.  Bit-identical, but 1 215 us per launch against 1 050 for the fused epilogue: 32 more in-order memory
+// operations per tile in the L segments cost +266 us (an L segment is the critical path of its slot: every request it issues delays the
+// barrier its partner's MFMAs wait for), the arithmetic in the M segments itself next to nothing.
 #include "gemm_common.h"
 
 namespace cgpt {
@@ -59,9 +41,7 @@ namespace {
 
 constexpr int kMaxDevices9 = 64;
 template <int V> struct IntTag9 { static constexpr int value = V; };
-constexpr int kDeferMinK = 18;                                             // K-tiles a successor needs to carry a deferred tile
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
@@ -84,7 +64,6 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     const int ntiles = tiles_m * tiles_n;
     const int nk = p.K / BK;
     const bool split_n = (p.N % 256) == 128 && p.N >= 384 && !(p.ablate & 16384);
-    const bool defer_on = GELU && p.defer_gelu && nk >= kDeferMinK;
 
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.W), 0, -1, 0x00020000);
@@ -151,42 +130,6 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         }
     };
 
-    // ------------------------------------------------------------------ deferred GELU of the previous tile (GELU kernels only)
-    // piece k (0..15) of this wave = rows 8k .. 8k+7 of its 128 x 64 output block; lane -> row lane>>3, 16-byte chunk lane&7 (the bytes
-    // this lane stored in the epilogue); slot k&1 of the wave's scratch (bytes 1024.. : the first 256 hold the bias), lane-linear
-    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, -1, 0x00020000);
-    unsigned d_off = 0;                                                     // wave-uniform byte offset of the pending block
-    bool pending = false;
-    u32x4 dv = {0u, 0u, 0u, 0u};                                            // the piece being computed: 8 fp16 values of this lane
-    half_t* const dslots = scratch_all + wave * 2048 + 512;                 // two 1-KiB slots behind the bias
-    auto lane_id = [&]() __attribute__((always_inline)) {                   // recomputed where needed: not kept across the K loop
-        int el;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
-        return el;
-    };
-    auto piece_voff = [&]() __attribute__((always_inline)) { const int el = lane_id(); return ((el >> 3) * (int)p.ldo + (el & 7) * 8) * 2; };
-    auto piece_off = [&](int k) { return __builtin_amdgcn_readfirstlane((int)(d_off + (unsigned)(8 * k) * (unsigned)p.ldo * 2u)); };
-    auto dload = [&](int k) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_o, (__attribute__((address_space(3))) void*)(dslots + (k & 1) * 512), 16, piece_voff(),
-                                                 piece_off(k), 0, /*sc1*/ 16);
-    };
-    auto dread = [&](int k, int half) __attribute__((always_inline)) {      // this lane's 8 bytes of half `half` of piece k
-        return *reinterpret_cast<const f16x4*>(dslots + (k & 1) * 512 + lane_id() * 8 + half * 4);
-    };
-    auto dstore = [&](int k) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_buffer_store_b128(dv, rs_o, piece_voff(), piece_off(k), /*nt*/ 2);
-    };
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    auto dgelu = [&](f16x4 h, int half) __attribute__((always_inline)) {
-#ifdef CGPT9_NO_DGELU
-        const u32x2 r = __builtin_bit_cast(u32x2, h);
-#else
-        const u32x2 r = __builtin_bit_cast(u32x2, gelu_h4(h));
-#endif
-        dv[2 * half] = r[0]; dv[2 * half + 1] = r[1];
-    };
-    f16x4 d_in = {0, 0, 0, 0};                                              // a half read in an L segment, computed in the next M segment
-
     // ------------------------------------------------------------------ compute side
     const int sw = (r15 >> 1) & 7;
     const int k_off0 = ((g ^ sw) << 3), k_off1 = (((4 + g) ^ sw) << 3);
@@ -234,27 +177,13 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         unsigned long long ts_k1 = 0;
 #endif
 
-        // One K-tile.  vmcnt bookkeeping (loads, stores and LDS-DMA retire in issue order): L(P0) of K-tile c issues l_c piece requests
-        // (0 or 1) and then 2 operand requests, L(P1) issues s_c piece stores (0 or 1) and then 6 operand requests.  The wait that ends
-        // L(P0) of c must retire A(m1) of c = the last 2 operations of L(P0) of c-1: it may leave s_(c-1) + 6 + l_c + 2 in flight.  The
-        // wait that ends L(P1) of c must retire A(m0), B(n0), B(n1) of c+1 = the last 6 of L(P1) of c-1, and the piece requested first in
-        // L(P0) of c: it may leave 2 + s_c + 6 in flight (the same count when there is no piece: l_c = 0).
-        // There are only TWO copies of this body: the first K-tile of a tile (Z: zero accumulator operand, never any deferred work) and
-        // the generic one, whose deferred memory operations (ld: request piece kt-1, st: store piece kt-2) and wait counts (n0, n2) are
-        // wave-uniform RUN-TIME values.  (One copy per row of the table above made the register allocator give the accumulators
-        // different registers in different copies and need 16 more for the permutations between them: spills, i.e. scratch
-        // loads inside the counted waits.)  The generic copy's GELU arithmetic is unconditional -- on stale scratch bytes when nothing
-        // is pending -- so that its M segments stay straight-line code the compiler can interleave with the MFMAs; only memory
-        // operations are predicated.
-        auto wait_vm = [&](int n) __attribute__((always_inline)) {
+        // One K-tile; two copies of this body: the first K-tile of a tile (Z: zero accumulator operand) and every other one.
+        auto wait_vm = [&]() __attribute__((always_inline)) {               // the four younger parts stay in flight
             if (!req_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (!GELU || n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         };
-        auto ktile = [&](auto zero_tag, int kt, bool ld, bool st_piece, int n0, int n2) __attribute__((always_inline)) {
+        auto ktile = [&](auto zero_tag) __attribute__((always_inline)) {
             constexpr bool Z = decltype(zero_tag)::value != 0;
-            constexpr bool DG = GELU && !Z;                                 // this copy carries the deferred-GELU arithmetic
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             const half_t* st = smem9 + (c & 1) * STAGE;
             // ---------------- P0 = (m0; n0, n1)
@@ -274,16 +203,10 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                 bf1[j][1] = *reinterpret_cast<const f16x8*>(st + b_rd + (2 + j) * 16 * BK + k_off1);
             }
             CGPT_FENCE
-            if constexpr (DG) {
-                d_in = dread(kt, 1);                                        // second half of piece kt-2 (slot parity of kt)
-                if (ld) dload(kt - 1);
-                CGPT_FENCE                                                  // the counts below assume this issue order
-            }
             request(IntTag9<3>{});                                          // A(m1) of K-tile c+1
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wait_vm(n0);                                                    // A(m1) of this K-tile has landed
+            wait_vm();                                                      // A(m1) of this K-tile has landed
             CGPT_SLOT_END
-            if constexpr (DG) dgelu(d_in, 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -306,15 +229,12 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                 af[i][1] = *reinterpret_cast<const f16x8*>(st + a_rd + (4 + i) * 16 * BK + k_off1);
             }
             CGPT_FENCE
-            if constexpr (DG) { if (st_piece) dstore(kt - 2); CGPT_FENCE }
             request(IntTag9<0>{});                                          // A(m0), B(n0), B(n1) of K-tile c+2: all last read in L(P0)
             request(IntTag9<1>{});
             request(IntTag9<2>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wait_vm(n2);                                                    // A(m0), B(n0), B(n1) of K-tile c+1 (and piece kt-1) have landed
-            if constexpr (DG) d_in = dread(kt - 1, 0);                      // first half; this wave's own request: no barrier needed
+            wait_vm();                                                      // A(m0), B(n0), B(n1) of K-tile c+1 have landed
             CGPT_SLOT_END
-            if constexpr (DG) dgelu(d_in, 0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -333,20 +253,11 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             ++c;
         };
 
-        ktile(IntTag9<1>{}, 0, false, false, 8, 8);
+        ktile(IntTag9<1>{});
 #ifdef CGPT_STAMPS
         ts_k1 = __builtin_amdgcn_s_memtime();
 #endif
-        {
-            const bool pend = GELU && pending;                              // nk >= kDeferMinK then; rows of the table in the header
-            for (int kt = 1; kt < nk; ++kt) {
-                const bool ld = pend && kt <= 16, stp = pend && kt >= 2 && kt <= 17;
-                const int n0 = !pend ? 8 : (kt >= 3 && kt <= 16) ? 10 : kt <= 18 ? 9 : 8;
-                const int n2 = stp ? 9 : 8;
-                ktile(IntTag9<0>{}, kt, ld, stp, n0, n2);
-            }
-            pending = false;
-        }
+        for (int kt = 1; kt < nk; ++kt) ktile(IntTag9<0>{});
 
 #ifdef CGPT_STAMPS
         const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
@@ -372,10 +283,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             // 128 B with the 16-byte chunk index XOR-swizzled by row & 7; a lane then stores 16 contiguous bytes, 8 lanes one line
             half_t* outp = reinterpret_cast<half_t*>(p.out);
             const int row_rd = el >> 3, ch_rd = el & 7;
-            // GELU of this tile is left to the successor's K loop when there is one (wide tiles only: a piece is 16 lanes x 8 bytes)
-            const bool defer_this = GELU && !NARROW && defer_on && t + (int)gridDim.x < ntiles;
-            auto passes = [&](auto raw_tag) __attribute__((always_inline)) {
-                constexpr bool RAW = decltype(raw_tag)::value != 0;
+            {
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
 #pragma unroll
@@ -386,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                         for (int jj = 0; jj < TNv; ++jj) {
                             const f32x4 v = acc[i][jj] + bias4[jj];
                             f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                            if constexpr (GELU && !RAW) hv = gelu_h4(hv);
+                            if constexpr (GELU) hv = gelu_h4(hv);
                             const int ch = (jj * 2 + (eg >> 1)) ^ (row & 7);
                             *reinterpret_cast<f16x4*>(scr + row * 64 + ch * 8 + (eg & 1) * 4) = hv;
                         }
@@ -399,19 +307,11 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                         const int row = it * 8 + row_rd;
                         if (!NARROW || ch_rd < 6) {
                             const f16x8 o = *reinterpret_cast<const f16x8*>(scr + row * 64 + ((ch_rd ^ (row & 7)) * 8));
-                            if constexpr (RAW) *reinterpret_cast<f16x8*>(dst0 + it * step) = o;   // re-read soon: default cache policy
-                            else CGPT9_STORE16(o, reinterpret_cast<f16x8*>(dst0 + it * step));
+                            CGPT9_STORE16(o, reinterpret_cast<f16x8*>(dst0 + it * step));
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads returned before the next pass overwrites
                 }
-            };
-            if (defer_this) {
-                passes(IntTag9<1>{});
-                pending = true;
-                d_off = (unsigned)(((int64_t)tm * BM2 + wr * 128) * p.ldo + ncol0 + wc * 64) * 2u;
-            } else {
-                passes(IntTag9<0>{});
             }
         } else {
             if constexpr (NARROW) {
@@ -450,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 }
 
 template <int EPI>
-hipError_t launch_v9(const GemmParams& p_in, hipStream_t stream) {
+hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
     constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t) + 32768;   // two stages + epilogue scratch = 160 KiB
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
@@ -465,10 +365,6 @@ hipError_t launch_v9(const GemmParams& p_in, hipStream_t stream) {
         cus[dev] = n > 0 ? n : 256;
         configured[dev] = true;
     }
-    GemmParams p = p_in;
-    // deferred GELU: wide tiles only (N a multiple of 256), 16-byte output rows, 32-bit offsets into the output
-    const int64_t out_bytes = ((int64_t)((p.M + 255) / 256) * 256) * p.ldo * 2;
-    p.defer_gelu = EPI == EPI_F16_GELU && (p.N % 256) == 0 && (p.ldo % 8) == 0 && out_bytes < ((int64_t)1 << 32) && !(p.ablate & 32768);
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = tiles < cus[dev] ? tiles : cus[dev];                   // one 512-thread workgroup per CU (LDS-limited), persistent
     hipLaunchKernelGGL((gemm9_f16_kernel<EPI>), dim3(grid), dim3(512), lds_bytes, stream, p);

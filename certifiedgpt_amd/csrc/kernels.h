@@ -29,7 +29,6 @@ struct GemmParams {
     unsigned long long* dbg = nullptr;   // diagnostic builds only (-DCGPT_STAMPS): per-wave cycle sums
     int group_m = 8;              // tile-rows per group in the block->tile map (speed only)
     int ablate = 0;               // lab builds: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs; tests: see launch_gemm
-    int defer_gelu = 0;           // set by the gemm9 launcher: EPI_F16_GELU finished inside the next tile's K loop
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
 // gemm9.hip: 256x256 tile, two 32-MFMA phases per K-tile, operand parts requested 1.5 K-tiles ahead by LDS-DMA

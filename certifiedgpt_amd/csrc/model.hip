@@ -779,8 +779,8 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
     }
     if (k == "gemm_ablate") {
 #ifndef CGPT_LAB
-        if (value & ~(512 | 16384 | 32768))
-            return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_ablate (test-only) accepts the result-preserving bits 512|16384|32768");
+        if (value & ~(512 | 16384))
+            return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_ablate (test-only) accepts the result-preserving bits 512|16384");
 #endif
         g_gemm_ablate = value;
         return CGPT_OK;

@@ -221,8 +221,7 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
  *                  automatic choice for M >= 1024 when the shape has more than 128 tiles of 256x256).
  *   "gemm_ablate": TEST-ONLY bit mask; each bit turns ONE optimisation of the 256x256 kernels off without changing a result, so that
  *                  the test suite can check that the bits do not depend on it: 512 = LDS-transposed fp16 epilogue, 16384 = 192-column
- *                  last tiles for N = 256k+128, 32768 = GELU finished inside the next tile's K loop (gemm9.hip).  Any other bit is
- *                  rejected with CGPT_ERR_INVALID.  Process-global and unsynchronised: set it only while no launch is in flight.
+ *                  last tiles for N = 256k+128.  Any other bit is rejected with CGPT_ERR_INVALID.  Process-global and unsynchronised: set it only while no launch is in flight.
  * (A lab build of the library -- make LAB=1, never shipped -- additionally accepts the experimental schedules 2, 5..11, 15 and
  * timing-study switches that skip work; profiles/r01/gemm_variants.txt.) */
 cgpt_status cgpt_set_option(const char* key, int32_t value);

@@ -1,6 +1,6 @@
-"""A/B of the deferred GELU (gemm9.hip) on the ViT-G MLP shapes at the bench's batch (255 samples = 65 535 rows): interleaved rounds in
-ONE process, per round: fc1 with the deferral (default), fc1 with GELU in the epilogue (gemm_ablate 32768), fc2 and fc1 without GELU
-(the floor).  Prints us per launch and TFLOP/s (median and min over rounds).  Run on the GPU box:  python tools/gemm_defer_ab.py [rounds]"""
+"""Raw timing of the four ViT-G GEMM shapes at the bench's batch (255 samples = 65 535 rows), interleaved rounds in ONE process: fc1 with
+its GELU epilogue, fc1 without GELU (what the epilogue costs), fc2, qkv, proj.  us per launch and TFLOP/s (median and min over rounds).
+CGPT_LIB_PATH selects another build of the library for an A/B on the same box.  python tools/gemm_shapes_bench.py [rounds]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C, statistics, torch
@@ -21,7 +21,7 @@ def launch(name, epi, abl):
     N = {"fc1": 6144, "fc2": 1408, "qkv": 4224, "proj": 1408}[name]
     _lib.check(L.cgpt_set_option(b"gemm_ablate", abl))
     _lib.check(L.cgpt_linear_f16(P(A), K, P(W), K, P(b), P(out), N, None, N, M, N, K, epi, st()))
-variants = [("fc1 + GELU deferred", "fc1", 1, 0), ("fc1 + GELU in epilogue", "fc1", 1, 32768), ("fc1 no GELU", "fc1", 0, 0), ("fc2", "fc2", 0, 0),
+variants = [("fc1 + GELU", "fc1", 1, 0), ("fc1 no GELU", "fc1", 0, 0), ("fc2", "fc2", 0, 0),
             ("qkv", "qkv", 0, 0), ("proj", "proj", 0, 0)]
 res = {v[0]: [] for v in variants}
 for v in variants:
