@@ -786,7 +786,7 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     const int force = vec_ok ? g_gemm_kernel : 1;   // 0 auto, 1 = 128x128 register-staged, 3 = 256x128 direct-to-LDS, 4 = 256x256 phased
     if (force == 3 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
     if (force == 4) return launch_v3_epi<4>(epilogue, p, stream);
-    if (force == 14 && v9_fits(p)) return launch_v9_epi(epilogue, p, stream);
+    if (force == 14) return launch_v9_epi(epilogue, p, stream);
 #ifdef CGPT_LAB
     if (force == 2) return launch_v2_epi<256>(epilogue, p, stream);
     if (force == 5) return launch_v3_epi<2>(epilogue, p, stream);
@@ -805,12 +805,11 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
         const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         if (tiles256 <= 128 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
 #ifdef CGPT_LAB
-        if (force == 15 && v9_fits(p)) return launch_v9_epi(epilogue, p, stream);          // lab: the two-phase quadrant kernel wherever the automatic choice is a 256x256 tile
+        if (force == 15) return launch_v9_epi(epilogue, p, stream);          // lab: the two-phase quadrant kernel wherever the automatic choice is a 256x256 tile
 #endif
         // the two-phase quadrant kernel (gemm9.hip) wins on every ViT shape in the model: qkv 650 -> 611, proj 238 -> 229,
         // fc1 + GELU ~1 000 -> 976, fc2 859 -> 823 us per 255-sample launch (profiles/r02/gemm_two_phase_variants.txt)
-        if (v9_fits(p)) return launch_v9_epi(epilogue, p, stream);
-        return launch_v3_epi<4>(epilogue, p, stream);                          // operands of 4 GiB or more: 64-bit addressing
+        return launch_v9_epi(epilogue, p, stream);
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

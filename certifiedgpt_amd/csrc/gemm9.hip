@@ -18,15 +18,18 @@
 // Every part is requested 6 slots = 1.5 K-tiles before its first read.  Both L segments end with a COUNTED s_waitcnt vmcnt(N) (never 0
 // in steady state: the four younger parts stay in flight), lgkmcnt(0) and the barrier, so a part is retired by EVERY wave at least one
 // barrier before any wave reads it, and re-requested at least one barrier after every wave's reads of it have returned.
-// Requests are `buffer_load_dwordx4 ... offen lds`: one 32-bit per-lane offset per piece (6 VGPRs in all) + a wave-uniform offset for
-// tile, K-tile and part, instead of eight 64-bit per-lane pointers.  The first K-tile of a tile multiplies into a ZERO accumulator
-// operand instead of clearing 128 registers.
+// The first K-tile of a tile multiplies into a ZERO accumulator operand instead of clearing 128 registers (round 3: -1.5 ... -2 % on the
+// K = 1408 shapes, raw harness).
 //
-// Tried and removed in round 3 (profiles/r03/gemm_deferred_gelu.txt): finishing fc1's GELU inside the NEXT tile's K loop -- raw fp16 tile
-// written by a plain epilogue, re-read in 1-KiB pieces by LDS-DMA into the idle epilogue scratch behind exactly re-counted waits, GELU in
-// the M segments, stored back.  Bit-identical, but 1 215 us per launch against 1 050 for the fused epilogue: 32 more in-order memory
-// operations per tile in the L segments cost +266 us (an L segment is the critical path of its slot: every request it issues delays the
-// barrier its partner's MFMAs wait for), the arithmetic in the M segments itself next to nothing.
+// Tried and removed in round 3 (profiles/r03/gemm_deferred_gelu.txt):
+//  * finishing fc1's GELU inside the NEXT tile's K loop -- raw fp16 tile written by a plain epilogue, re-read in 1-KiB pieces by LDS-DMA into
+//    the idle epilogue scratch behind exactly re-counted waits, GELU in the M segments, stored back.  Bit-identical, but 1 215 us per launch
+//    against 1 050 for the fused epilogue: 32 more in-order memory operations per tile in the L segments cost +266 us (an L segment is the
+//    critical path of its slot: every request it issues delays the barrier its partner's MFMAs wait for), the arithmetic in the M
+//    segments itself next to nothing.
+//  * requests as `buffer_load_dwordx4 ... offen lds` (one 32-bit per-lane offset per piece + a wave-uniform soffset: 6 VGPRs instead of
+//    eight 64-bit pointers, 247 -> 220 VGPRs): bit-identical, but the K loop is ~2 % slower (fc2 864 vs 846 us raw; 9.81 vs 10.00 img/s
+//    in the model on one box).
 #include "gemm_common.h"
 
 namespace cgpt {
@@ -45,7 +48,6 @@ template <int V> struct IntTag9 { static constexpr int value = V; };
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the body uses gfx950 buffer builtins the host pass of hipcc cannot type-check: the host sees only the stub
     constexpr int BM2 = 256, BN_ = 256;
     constexpr int A_ELEMS = BM2 * BK, STAGE = 2 * A_ELEMS;                 // halfs: A image then W image, 128-byte rows
     constexpr bool GELU = EPI == EPI_F16_GELU;
@@ -65,24 +67,16 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     const int nk = p.K / BK;
     const bool split_n = (p.N % 256) == 128 && p.N >= 384 && !(p.ablate & 16384);
 
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.W), 0, -1, 0x00020000);
-
     // ------------------------------------------------------------------ request side (runs ~1.5 K-tiles ahead of the MFMAs)
     // piece i (0, 1) of this wave covers part rows 16*(wave&3 | wave&1) + 8*i + (lane>>3); source 16-byte chunk swizzled per row.
     // A(m1) is A(m0) + 64 rows and (wide tiles) B(n1) is B(n0) + 32 rows: the swizzle (row >> 1) & 7 is the same, so they differ by a
     // wave-uniform offset.  All offsets are bytes.
     const int lr = lane >> 3, cpos = lane & 7;
-    const int ra = (wave >> 2) * 128 + 16 * (wave & 3);
-    int va[2], vb0[2], vb1[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r0 = ra + 8 * i + lr;
-        va[i] = (r0 * (int)p.lda + ((cpos ^ ((r0 >> 1) & 7)) << 3)) * 2;
-    }
-    const int dst_a0 = ra * BK, dst_a1 = (ra + 64) * BK;                    // LDS offsets (halfs) inside a stage, piece 0 (piece 1 = + 8 rows)
-    int dst_b0[2], dst_b1[2];
-    unsigned a_off = 0, w_off = 0;                                          // wave-uniform byte offsets of the request tile's A rows / W rows
+    const half_t* src_a0[2];   // A(m0): tile rows (wave>>2)*128 +  0 + 16*(wave&3) + 8*i + lr
+    const half_t* src_a1[2];   // A(m1):                        + 64
+    const half_t* src_b0[2];   // B(n0): W rows (wave>>1)*64 + 16*(wave&1) + 8*i + lr          (narrow: (wave>>1)*48 + ...)
+    const half_t* src_b1[2];   // B(n1):                    + 32                               (narrow: one piece, (wave>>1)*48 + 32 + 8*(wave&1) + lr)
+    int dst_a0, dst_a1, dst_b0[2], dst_b1[2];                               // LDS offsets (halfs) inside a stage, piece 0 (A: piece 1 = + 8 rows)
     int rt = blockIdx.x, rkt = 0, rc = 0;                                   // request cursor: tile, K-tile in it, stream K-tile counter
     bool req_ok = rt < ntiles;
     auto set_req_tile = [&](int t) {
@@ -90,36 +84,38 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn, p.group_m);
         const bool narrow = split_n && tn >= tiles_n - 2;
         const int ncol0 = narrow ? (tiles_n - 2) * BN_ + (tn - (tiles_n - 2)) * 192 : tn * BN_;
-        a_off = (unsigned)(tm * BM2) * (unsigned)p.lda * 2u;
-        w_off = (unsigned)ncol0 * (unsigned)p.ldw * 2u;
+        const int ra = (wave >> 2) * 128 + 16 * (wave & 3);
+        dst_a0 = ra * BK;
+        dst_a1 = (ra + 64) * BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            const int r0 = ra + 8 * i + lr, r1 = r0 + 64;
+            src_a0[i] = p.A + (int64_t)(tm * BM2 + r0) * p.lda + ((cpos ^ ((r0 >> 1) & 7)) << 3);
+            src_a1[i] = p.A + (int64_t)(tm * BM2 + r1) * p.lda + ((cpos ^ ((r1 >> 1) & 7)) << 3);
             // W rows of the two B parts (LDS row == row inside the tile's W image)
             const int b0 = narrow ? (wave >> 1) * 48 + 16 * (wave & 1) + 8 * i : (wave >> 1) * 64 + 16 * (wave & 1) + 8 * i;
             const int b1 = narrow ? (wave >> 1) * 48 + 32 + 8 * (wave & 1) : b0 + 32;   // narrow: both pieces are the same 8 rows (idempotent)
             dst_b0[i] = A_ELEMS + b0 * BK;
             dst_b1[i] = A_ELEMS + b1 * BK;
-            vb0[i] = ((b0 + lr) * (int)p.ldw + ((cpos ^ (((b0 + lr) >> 1) & 7)) << 3)) * 2;
-            vb1[i] = ((b1 + lr) * (int)p.ldw + ((cpos ^ (((b1 + lr) >> 1) & 7)) << 3)) * 2;
+            src_b0[i] = p.W + (int64_t)(ncol0 + b0 + lr) * p.ldw + ((cpos ^ (((b0 + lr) >> 1) & 7)) << 3);
+            src_b1[i] = p.W + (int64_t)(ncol0 + b1 + lr) * p.ldw + ((cpos ^ (((b1 + lr) >> 1) & 7)) << 3);
         }
     };
-    auto glds = [&](const __amdgpu_buffer_rsrc_t& rs, int voff, unsigned soff, int lds_off) __attribute__((always_inline)) {
-        // soff is wave-uniform; saying so keeps hipcc from wrapping the request in a readfirstlane (waterfall) loop
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem9 + lds_off), 16, voff,
-                                                 __builtin_amdgcn_readfirstlane((int)soff), 0, 0);
+    auto glds = [&](const half_t* src, int lds_off) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem9 + lds_off), 16, 0, 0);
     };
     // PART: 0 = A(m0), 1 = B(n0), 2 = B(n1), 3 = A(m1); the four parts of one K-tile are requested consecutively in this order
     auto request = [&](auto part_tag) __attribute__((always_inline)) {
         constexpr int PART = decltype(part_tag)::value;
         if (!req_ok) return;
         const int sbase = (rc & 1) * STAGE;
-        const unsigned koff = (unsigned)rkt * (BK * 2);
-        if constexpr (PART == 0) { glds(rs_a, va[0], a_off + koff, sbase + dst_a0); glds(rs_a, va[1], a_off + koff, sbase + dst_a0 + 8 * BK); }
-        if constexpr (PART == 1) { glds(rs_w, vb0[0], w_off + koff, sbase + dst_b0[0]); glds(rs_w, vb0[1], w_off + koff, sbase + dst_b0[1]); }
-        if constexpr (PART == 2) { glds(rs_w, vb1[0], w_off + koff, sbase + dst_b1[0]); glds(rs_w, vb1[1], w_off + koff, sbase + dst_b1[1]); }
+        const int koff = rkt * BK;
+        if constexpr (PART == 0) { glds(src_a0[0] + koff, sbase + dst_a0); glds(src_a0[1] + koff, sbase + dst_a0 + 8 * BK); }
+        if constexpr (PART == 1) { glds(src_b0[0] + koff, sbase + dst_b0[0]); glds(src_b0[1] + koff, sbase + dst_b0[1]); }
+        if constexpr (PART == 2) { glds(src_b1[0] + koff, sbase + dst_b1[0]); glds(src_b1[1] + koff, sbase + dst_b1[1]); }
         if constexpr (PART == 3) {
-            const unsigned o = a_off + koff + 64u * (unsigned)p.lda * 2u;
-            glds(rs_a, va[0], o, sbase + dst_a1); glds(rs_a, va[1], o, sbase + dst_a1 + 8 * BK);
+            glds(src_a1[0] + koff, sbase + dst_a1); glds(src_a1[1] + koff, sbase + dst_a1 + 8 * BK);
             ++rc;                                                           // K-tile complete: advance the cursor
             if (++rkt == nk) {
                 rkt = 0;
@@ -346,7 +342,6 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #endif
 #undef CGPT_FENCE
 #undef CGPT_SLOT_END
-#endif  // __HIP_DEVICE_COMPILE__
 }
 
 template <int EPI>
@@ -372,12 +367,6 @@ hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
 }
 
 }  // namespace
-
-// 32-bit offsets into A and W (buffer addressing): the caller falls back to the phased kernel for operands of 4 GiB or more
-bool v9_fits(const GemmParams& p) {
-    const int64_t a_bytes = ((int64_t)((p.M + 255) / 256) * 256) * p.lda * 2, w_bytes = ((int64_t)((p.N + 255) / 256) * 256) * p.ldw * 2;
-    return a_bytes < ((int64_t)1 << 32) && w_bytes < ((int64_t)1 << 32) && p.lda * 640 < ((int64_t)1 << 31) && p.ldw * 640 < ((int64_t)1 << 31);
-}
 
 hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
     switch (epilogue) {

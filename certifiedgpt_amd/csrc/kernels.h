@@ -33,7 +33,6 @@ struct GemmParams {
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
 // gemm9.hip: 256x256 tile, two 32-MFMA phases per K-tile, operand parts requested 1.5 K-tiles ahead by LDS-DMA
 hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream);
-bool v9_fits(const GemmParams& p);   // its 32-bit buffer offsets cover the operands
 #ifdef CGPT_LAB
 hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);   // lab/gemm6.hip: 4-wave 128x128 wave tiles
 hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // lab/gemm8.hip: two 4-wave workgroups per CU, 128x256 tiles

@@ -414,4 +414,7 @@ def test_gelu_epilogue_rounds_the_linear_output_to_fp16_first_on_every_kernel(M,
     assert bool((ref[M:] == 5.0).all())
     want = torch.nn.functional.gelu(h[:M].float())
     err = (ref[:M].float() - want).abs()
-    assert bool((err <= 6e-4 * want.abs() + 1e-7).all()), float((err / (6e-4 * want.abs() + 1e-7)).max())
+    tol = 1.1e-3 * want.abs() + 2e-7          # fp16 output rounding (<= 2^-11 relative) + the polynomial's 0.05 % in the negative tail
+    assert bool((err <= tol).all()), float((err / tol).max())
+    big = want.abs() > 1e-2                    # away from the tail the approximation error is below fp32 resolution: rounding only
+    assert bool((err[big] <= 5.2e-4 * want.abs()[big]).all()), float((err[big] / want.abs()[big]).max())
