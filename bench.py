@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--img-size", type=int, default=224)
     ap.add_argument("--n", type=int, default=N)      # BASELINE configs[3]: --n 1000 (sharded 125 / GPU at 8 GPUs)
     ap.add_argument("--n0", type=int, default=N0)
+    ap.add_argument("--decode", choices=["graph", "hf"], default="graph")   # --workload minigpt4: greedy decode as one hipGraph | HF generate
     args = ap.parse_args()
     headline = args.workload == "vit_head" and args.img_size == 224 and args.n == N and args.n0 == N0
     n_est, n_sel = args.n, args.n0
@@ -202,7 +203,7 @@ def main():
     # Classifier batch capacity.  Smooth.certify_many cuts the (image, sample) rows of a group of images into batches of this
     # size, not aligned to image boundaries, so it is chosen for the GEMMs: 255 samples x 257 tokens = 65 535 rows = 256 tile
     # rows of 256 -> every GEMM's tile count is a multiple of the 256 CUs (200 samples: 201 tile rows, 96 % tile efficiency).
-    per_gpu = 200 if (rgf or args.img_size != 224) else (100 if gen else 255)
+    per_gpu = 200 if (rgf or gen or args.img_size != 224) else 255
     group = 1 if (rgf or gen) else 51                                 # images per certify_many call (51 x 200 = 40 x 255)
     if os.environ.get("CGPT_BENCH_BATCH"):                            # measurement only: "capacity,group"
         per_gpu, group = (int(v) for v in os.environ["CGPT_BENCH_BATCH"].split(","))
@@ -235,7 +236,8 @@ def main():
         probe = MiniGPT4Classifier(clf, llm, tok, prompt, AnswerLabelMap(NUM_CLASSES), max_new_tokens=20, max_batch=per_gpu)
         emb = clf.encode_img_noisy(images[0], 0, per_gpu, SIGMA, 42)
         vocab = sorted(set(probe.generate_from_embeds(emb, prompt)))[:NUM_CLASSES - 1]
-        base = MiniGPT4Classifier(clf, llm, tok, prompt, AnswerLabelMap(NUM_CLASSES, vocab, frozen=True), max_new_tokens=20, max_batch=per_gpu)
+        base = MiniGPT4Classifier(clf, llm, tok, prompt, AnswerLabelMap(NUM_CLASSES, vocab, frozen=True), max_new_tokens=20, max_batch=per_gpu,
+                                  decode=args.decode)
     smooth = cg.Smooth(base, NUM_CLASSES, SIGMA, seed=42, non_certifiable=(base.label_map.other_id,) if gen else ())
     torch.cuda.synchronize()
 
@@ -283,19 +285,39 @@ def main():
     # MI355X guide prescribes for gfx950) cannot be collected from inside this process; the committed summary of the same
     # command under profiles/ is reported when it matches this configuration (batch), else null.
     traffic, traffic_note = None, "no PMC summary for this configuration"
+    FC1_KERNEL = "gemm9_f16_kernel<1>"                 # roofline.kernel as rocprofv3 names it
     try:
-        with open(os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")) as f:
-            pm = json.load(f)["fc1"]
-        if world == 1 and headline:
+        import glob
+        import hashlib
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")))
+        if not cands:
+            raise FileNotFoundError("profiles/r*/pmc_summary.json")
+        newest = cands[-1]                                             # the newest round directory that holds a summary
+        with open(newest) as f:
+            summ = json.load(f)
+        pm, meta = summ["fc1"], summ.get("_meta", {})
+        rel = os.path.relpath(newest, ROOT)
+        lib_sha = hashlib.sha256(open(cg._lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+        if not (world == 1 and headline):
+            traffic_note = "PMC summary %s is for the single-GPU headline configuration" % rel
+        elif FC1_KERNEL not in pm.get("kernel_name", ""):
+            traffic_note = "PMC summary %s (commit %s) is for kernel %r, not %s: traffic withheld" % (
+                rel, meta.get("git_head"), pm.get("kernel_name"), FC1_KERNEL)
+        elif meta.get("batch_size_per_gpu") != per_gpu:
+            traffic_note = "PMC summary %s was taken at batch %s, this run uses %d: traffic withheld" % (rel, meta.get("batch_size_per_gpu"), per_gpu)
+        else:
             traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
-            traffic_note = ("bytes per launch from profiles/r02/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                            "FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted): read %.0f MB + write %.0f MB vs "
-                            "algorithmic %.0f MB (A %.0f + W %.0f + out %.0f; full %d-sample batches)" % (
+            same = meta.get("libcgpt_sha256_16") == lib_sha
+            traffic_note = ("bytes per launch of %s from %s, taken at commit %s (%s this run's libcgpt.so; rocprofv3 --pmc FETCH_SIZE / "
+                            "WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted): read %.0f MB + "
+                            "write %.0f MB vs algorithmic %.0f MB (A %.0f + W %.0f + out %.0f; full %d-sample batches)" % (
+                                pm["kernel_name"].split("(")[0][-40:], rel, meta.get("git_head"),
+                                "the same build as" if same else "a DIFFERENT build than",
                                 pm["hbm_read_bytes_corrected"] / 1e6, pm["hbm_write_bytes"] / 1e6,
                                 (per_gpu * 257 * (1408 + 6144) * 2 + 6144 * 1408 * 2) / 1e6, per_gpu * 257 * 1408 * 2 / 1e6,
                                 6144 * 1408 * 2 / 1e6, per_gpu * 257 * 6144 * 2 / 1e6, per_gpu))
-    except Exception:
-        pass
+    except Exception as e:
+        traffic_note = "no usable PMC summary under profiles/ (%r)" % (e,)
 
     fc1_ms, fc1_flops, fc1_n = clf.profile_read(1)
     by_kind = {}
@@ -320,6 +342,35 @@ def main():
         barrier()
         single_ms = 1e3 * (time.perf_counter() - ts) / reps
 
+    gen_report = None
+    if gen:
+        # where a certified image's time goes (one 200-row batch, HIP events), and what the graph decode changes against HF generate
+        def timed(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                out = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps, out
+        x0 = images[0]
+        enc_ms, emb = timed(lambda: clf.encode_img_noisy(x0, 0, per_gpu, SIGMA, 42))
+        segs = base._segment_embeddings(prompt, dev)
+        embs = torch.cat([segs[0].expand(per_gpu, -1, -1), emb.to(segs[0].dtype), segs[1].expand(per_gpu, -1, -1)], dim=1)
+        hf = MiniGPT4Classifier(clf, llm, tok, prompt, base.label_map, max_new_tokens=20, max_batch=per_gpu, decode="hf")
+        gr = MiniGPT4Classifier(clf, llm, tok, prompt, base.label_map, max_new_tokens=20, max_batch=per_gpu, decode="graph")
+        hf_ms, a_hf = timed(lambda: hf.generate_from_embeds(emb, prompt), reps=2)
+        gr_ms, a_gr = timed(lambda: gr.generate_from_embeds(emb, prompt), reps=2)
+        with torch.no_grad():
+            pre_ms, _ = timed(lambda: llm(inputs_embeds=embs, use_cache=True, logits_to_keep=1).logits, reps=2)
+        gen_report = {"rows_per_batch": per_gpu, "prompt_tokens_incl_32_image_tokens": int(embs.shape[1]),
+                      "encode_img_ms": enc_ms, "hf_generate_ms": hf_ms, "graph_decode_ms": gr_ms, "prefill_alone_ms": pre_ms,
+                      "per_token_step_ms_hf": (hf_ms - pre_ms) / 19.0, "per_token_step_ms_graph": (gr_ms - pre_ms) / 19.0,
+                      "answers_identical_rows": sum(int(a == b) for a, b in zip(a_hf, a_gr)), "decode": args.decode,
+                      "decode_stats": base.decode_stats}
+
     if rank == 0:
         value = args.steps / elapsed
         fc1_tflops = fc1_flops / (fc1_ms * 1e-3) / 1e12 if fc1_ms > 0 else 0.0
@@ -341,7 +392,7 @@ def main():
                                        f"batches, one int64[G,2,{NUM_CLASSES}] all-reduce per call)")},
             "forwards_per_s": value * (N0 + N),
             "vit_tflops_end_to_end": value * (N0 + N) * F_VIT / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm9_f16_kernel<EPI_F16_GELU, two-phase> (ViT MLP fc1 + GELU, M=batch*257, N=6144, K=1408)",
+            "roofline": {"bound": "mfma", "kernel": "gemm9_f16_kernel<1> = <EPI_F16_GELU> (ViT MLP fc1 + GELU, M=batch*257, N=6144, K=1408)",
                          "achieved": fc1_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": fc1_tflops / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "launches": fc1_n, "avg_launch_ms": fc1_ms / max(fc1_n, 1),
@@ -359,9 +410,11 @@ def main():
             what = (f"8-step RGF attack (1 direction per step) + smoothed predict, {attack.forwards_per_image(n_est)} forwards per image"
                     if rgf else f"Smooth.certify n0={n_sel} n={n_est} alpha=0.001 sigma=0.5")
             if gen:
-                what += (" over full MiniGPT-4: encode_img in HIP + random-init decoder of the Vicuna-7B architecture (fp16, HF generate on "
-                         "PyTorch-ROCm, 20 new tokens per noisy copy, batches of %d), answers -> classes by a frozen vocabulary of %d answers "
-                         "(BASELINE configs[2])" % (per_gpu, len(base.label_map.answers)))
+                what += (" over full MiniGPT-4: encode_img in HIP + random-init decoder of the Vicuna-7B architecture (fp16, greedy decode on "
+                         "PyTorch-ROCm: %s; 20 new tokens per noisy copy, batches of %d), answers -> classes by a frozen vocabulary of %d "
+                         "answers (BASELINE configs[2])" % ("prefill + 19 steps replayed from one hipGraph" if args.decode == "graph" else
+                                                            "HF generate", per_gpu, len(base.label_map.answers)))
+                line["minigpt4_phases"] = gen_report
             line["config"]["workload"] = (f"NON-HEADLINE data point: mode={mode}, image {args.img_size}x{args.img_size} (T={T}), "
                                           f"random-init weights, {what}")
             line["config"].update({"n0": n_sel, "n": n_est})

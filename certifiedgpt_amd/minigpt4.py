@@ -96,7 +96,7 @@ class MiniGPT4Classifier:
     """
 
     def __init__(self, encoder, llama_model, llama_tokenizer, prompt, label_map, max_new_tokens=20, max_batch=None,
-                 generate_kwargs=None):
+                 generate_kwargs=None, decode="hf"):
         self.encoder = encoder
         self.llama_model = llama_model
         self.llama_tokenizer = llama_tokenizer
@@ -110,6 +110,14 @@ class MiniGPT4Classifier:
                                     temperature=1, do_sample=False)
         self.generate_kwargs.update(generate_kwargs or {})
         self.last_answers = []
+        # decode = "hf": `llama_model.generate(...)` exactly as the reference calls it (minigpt_base.py:418-431).
+        # decode = "graph": the same greedy decode -- the model's own forward for the prefill and for every step, a DynamicCache, EOS
+        #   suppressed on the first token (min_length = 1), pad after EOS -- written as a fixed-length loop without host round trips and
+        #   replayed from ONE hipGraph per (batch, prompt length); shared prompts on a HIP device only, everything else takes "hf".
+        assert decode in ("hf", "graph")
+        self.decode = decode
+        self._graphs = {}
+        self.decode_stats = {"graph_replays": 0, "graph_captures": 0, "hf_calls": 0}
 
     # ---- nn.Module-shaped surface used by Smooth (smoothing.py:42,71)
     def eval(self):
@@ -161,14 +169,87 @@ class MiniGPT4Classifier:
             for i, emb in enumerate(batch_embs):                       # left padding, minigpt_base.py:413-416
                 embs[i, -emb.shape[1]:] = emb[0]
                 attn_mask[i, -emb.shape[1]:] = 1
-        outputs = self.llama_model.generate(inputs_embeds=embs, attention_mask=attn_mask, max_new_tokens=self.max_new_tokens,
-                                            **self.generate_kwargs)
+        shared = isinstance(texts, str) or len(set(texts)) == 1
+        if self.decode == "graph" and shared and embs.is_cuda and self._greedy_defaults():
+            outputs = self._generate_graph(embs)
+        else:
+            self.decode_stats["hf_calls"] += 1
+            outputs = self.llama_model.generate(inputs_embeds=embs, attention_mask=attn_mask, max_new_tokens=self.max_new_tokens,
+                                                **self.generate_kwargs)
+        return self._decode_outputs(outputs)
+
+    def _decode_outputs(self, outputs):
+        """minigpt_base.py:440-447."""
         answers = []
         for output_token in outputs:
             if output_token[0] == 0:
                 output_token = output_token[1:]
             answers.append(clean_answer(self.llama_tokenizer.decode(output_token, skip_special_tokens=True)))
         return answers
+
+    # ---- greedy decode without host round trips (decode = "graph")
+    def _greedy_defaults(self):
+        k = self.generate_kwargs
+        return (k.get("num_beams", 1) == 1 and not k.get("do_sample", False) and k.get("repetition_penalty", 1) == 1
+                and k.get("min_length", 1) == 1)
+
+    def greedy_tokens(self, embs):
+        """What `generate(inputs_embeds=embs, attention_mask=ones, max_new_tokens=n, do_sample=False, min_length=1, ...)` returns for
+        prompts without padding, as a straight loop of the model's own forward calls: [B, n] token ids, pad_token_id after a row's
+        EOS.  (HF additionally stops, and truncates, at the step where every row has finished; the extra columns here are pad ids,
+        which decode to nothing.)  No data-dependent control flow: capturable as one graph."""
+        from transformers import DynamicCache
+        llm = self.llama_model
+        gen = getattr(llm, "generation_config", None)
+        eos = getattr(gen, "eos_token_id", None)
+        eos = getattr(llm.config, "eos_token_id", None) if eos is None else eos
+        eos_ids = list(eos) if isinstance(eos, (list, tuple)) else ([eos] if eos is not None else [])
+        pad = getattr(gen, "pad_token_id", None)
+        pad = getattr(llm.config, "pad_token_id", None) if pad is None else pad
+        pad = (eos_ids[0] if eos_ids else 0) if pad is None else pad
+        B, L, _ = embs.shape
+        cache = DynamicCache(config=llm.config)
+        pos = torch.arange(L, device=embs.device).unsqueeze(0)
+        out = llm(inputs_embeds=embs, position_ids=pos, past_key_values=cache, use_cache=True, logits_to_keep=1)
+        logits = out.logits[:, -1, :].float()
+        if eos_ids:                                                    # MinLengthLogitsProcessor(min_length = 1): no EOS first
+            logits[:, eos_ids] = float("-inf")
+        unfinished = torch.ones(B, dtype=torch.long, device=embs.device)
+        tokens = []
+        for i in range(self.max_new_tokens):
+            nxt = logits.argmax(dim=-1)
+            nxt = nxt * unfinished + pad * (1 - unfinished)
+            tokens.append(nxt)
+            for e in eos_ids:
+                unfinished = unfinished * (nxt != e).long()
+            if i + 1 == self.max_new_tokens:
+                break
+            pos = torch.full((1, 1), L + i, device=embs.device, dtype=torch.long)
+            out = llm(input_ids=nxt[:, None], position_ids=pos, past_key_values=cache, use_cache=True, logits_to_keep=1)
+            logits = out.logits[:, -1, :].float()
+        return torch.stack(tokens, dim=1)
+
+    def _generate_graph(self, embs):
+        key = (embs.shape[0], embs.shape[1], embs.dtype)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = embs.clone()
+            side = torch.cuda.Stream(device=embs.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                              # warm-up outside the capture (lazy initialisations)
+                self.greedy_tokens(static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.greedy_tokens(static_in)
+            entry = (graph, static_in, static_out)
+            self._graphs[key] = entry
+            self.decode_stats["graph_captures"] += 1
+        graph, static_in, static_out = entry
+        static_in.copy_(embs)
+        graph.replay()
+        self.decode_stats["graph_replays"] += 1
+        return static_out.clone()
 
     @torch.no_grad()
     def generate(self, images, texts, **_ignored):
@@ -186,6 +267,31 @@ class MiniGPT4Classifier:
         for lo in range(0, images.shape[0], self.max_batch):
             out.append(self._logits(self.generate(images[lo:lo + self.max_batch], self.prompt), images.device))
         return torch.cat(out)
+
+    def sample_counts_pair(self, x, first_a, num_a, first_b, num_b, batch_size, sigma, seed):
+        """Selection + estimation draws of one `certify` (smoothing.py:44,48) in the same classifier batches: [2, num_classes] int64,
+        identical to two `sample_counts` calls (a row's answer does not depend on its batch: tested)."""
+        counts = torch.zeros((2, self.num_classes), dtype=torch.int64, device=x.device)
+        if first_b != first_a + num_a:                                 # not one contiguous index range: two passes
+            self.sample_counts(x, first_a, num_a, batch_size, sigma, seed, counts[0])
+            self.sample_counts(x, first_b, num_b, batch_size, sigma, seed, counts[1])
+            return counts
+        bs = max(1, min(int(batch_size), self.max_batch))
+        total, done, answers = num_a + num_b, 0, []
+        while done < total:
+            nb = min(bs, total - done)
+            emb = self.encoder.encode_img_noisy(x, first_a + done, nb, float(sigma), int(seed))
+            batch_answers = self.generate_from_embeds(emb, self.prompt)
+            logits = self.label_map.one_hot_logits(batch_answers, x.device)
+            na = max(0, min(nb, num_a - done))                         # rows of this batch that belong to the selection range
+            if na > 0:
+                vote(logits[:na], counts[0])
+            if nb - na > 0:
+                vote(logits[na:], counts[1])
+            answers += batch_answers
+            done += nb
+        self.last_answers = answers
+        return counts
 
     # ---- the `_sample_noise` engine (smoothing.py:81-99): noise fused into encode_img, vote in HIP
     def sample_counts(self, x, first_sample, num, batch_size, sigma, seed, counts=None):

@@ -115,3 +115,38 @@ def test_certify_agent_drives_the_generating_classifier(minigpt4, tmp_path):
         assert r["predict"] == cg.Smooth.ABSTAIN or 0 <= r["predict"] < len(vocab)      # "other" is never certified
     lines = open(tmp_path / "certify.tsv").read().strip().splitlines()
     assert len(lines) == 3
+
+
+def test_graph_decode_gives_the_answers_of_hf_generate(minigpt4):
+    """decode="graph": prefill + every greedy step through the model's own forward, captured once per (batch, prompt length) into one
+    hipGraph and replayed -- against `llama_model.generate` with the reference's arguments (decode="hf"), answer by answer, over full
+    and ragged batches (each batch size captures its own graph), and the certify that rides on it."""
+    enc, llm, cfg = minigpt4
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    sigma, seed = 2.0, 7
+    lm = AnswerLabelMap(4, ())
+    hf = MiniGPT4Classifier(enc, llm, ToyTokenizer(), PROMPT, lm, max_new_tokens=5, decode="hf")
+    gr = MiniGPT4Classifier(enc, llm, ToyTokenizer(), PROMPT, lm, max_new_tokens=5, decode="graph")
+    for first, num in ((0, 8), (8, 8), (16, 5), (21, 8), (29, 1)):
+        emb = enc.encode_img_noisy(x0, first, num, sigma, seed)
+        assert gr.generate_from_embeds(emb, PROMPT) == hf.generate_from_embeds(emb, PROMPT), (first, num)
+    assert gr.decode_stats["graph_captures"] == 3 and gr.decode_stats["graph_replays"] == 5 and gr.decode_stats["hf_calls"] == 0
+    # ragged prompts are not the Monte-Carlo case: they take the HF path
+    emb = enc.encode_img_noisy(x0, 0, 2, sigma, seed)
+    texts = prepare_texts(["<ImageHere> short", "<ImageHere> a longer question here"])
+    assert gr.generate_from_embeds(emb, texts) == hf.generate_from_embeds(emb, texts) and gr.decode_stats["hf_calls"] == 1
+    # certify through the pair pass (selection + estimation draws in the same batches) on both decoders
+    answers = hf.generate_from_embeds(enc.encode_img_noisy(x0, 0, 40, sigma, seed), PROMPT)
+    vocab = sorted(set(answers))[:5]
+    K = len(vocab) + 1
+    outs = []
+    for decode in ("hf", "graph"):
+        clf = MiniGPT4Classifier(enc, llm, ToyTokenizer(), PROMPT, AnswerLabelMap(K, vocab), max_new_tokens=5, decode=decode)
+        s = cg.Smooth(clf, K, sigma, seed=seed, non_certifiable=(clf.label_map.other_id,))
+        outs.append((s.certify(x0, 16, 24, 0.05, 8), list(clf.last_answers)))
+        s.reset()
+        two = (s._sample_noise(x0, 16, 8).tolist(), s._sample_noise(x0, 24, 8).tolist())
+        s.reset()
+        pair = s._sample_noise_pair(x0, 16, 24, 8)
+        assert (pair[0].tolist(), pair[1].tolist()) == two
+    assert outs[0] == outs[1] and outs[0][1] == answers

@@ -51,6 +51,65 @@ def test_reference_generate_goldens_pin_the_oracle_and_the_product(golden):
     assert n == 6
 
 
+def test_graph_decode_loop_reproduces_the_reference_generate_goldens(golden):
+    """`greedy_tokens` -- the fixed-length greedy loop that decode="graph" captures into one hipGraph (prefill + every step through the
+    model's own forward, EOS suppressed on the first token, pad after EOS) -- gives the answers the reference's
+    `MiniGPTBase.generate` gave for the shared-prompt cases (a CPU run of the same loop; the capture itself is a GPU test)."""
+    meta, arrays, llm = golden
+    n = 0
+    for case in meta["cases"]:
+        if "max_new_tokens" not in case or len(set(case["texts"])) != 1:
+            continue
+        clf = _gold_classifier(llm, case["max_new_tokens"])
+        emb = torch.from_numpy(arrays[case["embeds"]])
+        segs = clf._segment_embeddings(case["texts"][0], emb.device)
+        embs = torch.cat([segs[0].expand(len(emb), -1, -1), emb, segs[1].expand(len(emb), -1, -1)], dim=1)
+        with torch.no_grad():
+            toks = clf.greedy_tokens(embs)
+        assert toks.shape == (len(emb), case["max_new_tokens"])
+        assert clf._decode_outputs(toks) == case["answers"], case["name"]
+        n += 1
+    assert n == 4
+
+
+def test_pair_pass_equals_two_passes():
+    """`sample_counts_pair` (selection + estimation draws of one certify in the same batches) is host logic around the encoder, the
+    decoder and the vote; with a CPU stub encoder it must split a contiguous index range exactly like two `sample_counts` calls."""
+    import certifiedgpt_amd.minigpt4 as m
+
+    class Enc(StubEncoder):
+        max_batch = 8
+
+        def encode_img_noisy(self, x, first, num, sigma, seed):
+            g = torch.Generator().manual_seed(1000)
+            table = torch.randn(64, 3, generator=g)
+            imgs = x[None] + sigma * table[first:first + num, :, None, None]
+            return self.encode_img(imgs)[0]
+
+    def cpu_vote(logits, counts):
+        counts += torch.bincount(logits.argmax(1), minlength=counts.numel())
+
+    old, m.vote = m.vote, cpu_vote
+    try:
+        llm = tiny_llama()
+        probe = MiniGPT4Classifier(Enc(), llm, ToyTokenizer(), PROMPT, AnswerLabelMap(6, ()), max_new_tokens=3)
+        x = torch.randn(3, 8, 8)
+        answers = probe.generate_from_embeds(probe.encoder.encode_img_noisy(x, 0, 40, 2.0, 0), PROMPT)
+        vocab = sorted(set(answers))[:5]
+        clf = MiniGPT4Classifier(Enc(), llm, ToyTokenizer(), PROMPT, AnswerLabelMap(6, vocab), max_new_tokens=3)
+        for na, nb, bs in ((16, 24, 7), (5, 3, 8), (0, 9, 4), (9, 0, 4)):
+            pair = clf.sample_counts_pair(x, 0, na, na, nb, bs, 2.0, 0)
+            assert len(clf.last_answers) == na + nb
+            a = clf.sample_counts(x, 0, na, bs, 2.0, 0)
+            b = clf.sample_counts(x, na, nb, bs, 2.0, 0)
+            assert pair[0].tolist() == a.tolist() and pair[1].tolist() == b.tolist(), (na, nb, bs)
+            assert int(pair.sum()) == na + nb
+        gap = clf.sample_counts_pair(x, 0, 4, 10, 4, 8, 2.0, 0)                 # not contiguous: two passes
+        assert gap[0].tolist() == clf.sample_counts(x, 0, 4, 8, 2.0, 0).tolist()
+    finally:
+        m.vote = old
+
+
 def test_reference_context_embedding_goldens(golden):
     meta, arrays, llm = golden
     clf = _gold_classifier(llm, 6)

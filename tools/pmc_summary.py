@@ -7,18 +7,30 @@ import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "pmc_summary")
 GROUPS = [["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"], ["TCC_HIT_sum", "TCC_MISS_sum"]]
-KERNELS = {"layernorm": "layernorm4_", "gemm_f16out": "gemm9_f16_kernel<0, true>", "attention": "attention_kernel<88", "fc1": "gemm9_f16_kernel<1, true>"}
+KERNELS = {"layernorm": "layernorm4_", "gemm_f16out": "gemm9_f16_kernel<0>", "attention": "attention_kernel<88", "fc1": "gemm9_f16_kernel<1>"}
+BENCH_ARGS = ["--steps", "5", "--warmup", "1", "--no-cpu-baseline"]   # the default bench command (batches of 255, 255, 255, 235 samples + the 200-sample warm-up)
+
+
+def git_head():
+    """Commit of the tree the counters were taken on (the GPU box receives a snapshot without .git: the caller passes it in CGPT_GIT_HEAD)."""
+    if os.environ.get("CGPT_GIT_HEAD"):
+        return os.environ["CGPT_GIT_HEAD"]
+    try:
+        return subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True, check=True).stdout.strip()
+    except Exception:
+        return None
+
 
 
 def main():
-    round_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r01")
+    round_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03")
     os.makedirs(OUT, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     res = {k: {} for k in KERNELS}
     for i, grp in enumerate(GROUPS):
         d = os.path.join(OUT, f"p{i}")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *grp, "-d", d, "-o", "r", "--output-format", "csv", "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline"]   # the default bench command (batches of 255, 255, 255, 235 samples + the 200-sample warm-up)
+               sys.executable, os.path.join(ROOT, "bench.py"), *BENCH_ARGS]
         with open(os.path.join(OUT, f"p{i}.log"), "w") as log:
             subprocess.run(cmd, cwd=ROOT, env=env, stdout=log, stderr=subprocess.STDOUT, check=False)
         f = glob.glob(os.path.join(d, "**", "r_counter_collection.csv"), recursive=True)
@@ -37,6 +49,7 @@ def main():
             if not names:
                 continue
             n = names[0]
+            res[key]["kernel_name"] = n
             res[key]["launches"] = len(dur[n])
             for c in grp:
                 if vals[n][c]:
@@ -54,9 +67,16 @@ def main():
         if "TCC_HIT_sum" in r:
             r["l2_hit_rate"] = r["TCC_HIT_sum"] / max(r["TCC_HIT_sum"] + r["TCC_MISS_sum"], 1.0)
     os.makedirs(round_dir, exist_ok=True)
+    import hashlib
+    lib = os.path.join(ROOT, "certifiedgpt_amd", "libcgpt.so")
+    res["_meta"] = {"git_head": git_head(), "command": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py " + " ".join(BENCH_ARGS),
+                    "counter_groups": GROUPS, "batch_size_per_gpu": 255,
+                    "libcgpt_sha256_16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
+                    "note": "per-launch averages over every launch of the kernel in the run; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x2 "
+                            "(gfx950 correction, MI355X_MICROARCH.md); Infinity-Cache hits are counted"}
     with open(os.path.join(round_dir, "pmc_summary.json"), "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps({k: {c: v for c, v in r.items() if c in ("launches", "hbm_read_bytes_corrected", "hbm_write_bytes", "clock_ghz", "mfma_busy_frac", "l2_hit_rate")} for k, r in res.items()}, indent=1))
+    print(json.dumps({k: {c: v for c, v in r.items() if c in ("launches", "hbm_read_bytes_corrected", "hbm_write_bytes", "clock_ghz", "mfma_busy_frac", "l2_hit_rate", "kernel_name")} for k, r in res.items() if k != "_meta"}, indent=1))
 
 
 if __name__ == "__main__":
