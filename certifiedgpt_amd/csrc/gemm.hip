@@ -371,8 +371,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_f16_kernel(GemmParams p) {
         }
         if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n);
         if constexpr (EPI == EPI_F16 || EPI == EPI_F16_GELU) {
-            f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            if constexpr (EPI == EPI_F16_GELU) hv = gelu_h4(hv);
+            f16x4 hv;
+            if constexpr (EPI == EPI_F16_GELU) hv = gelu_f16x4(v);
+            else hv = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             *reinterpret_cast<f16x4*>(reinterpret_cast<half_t*>(p.out) + orow + n) = hv;
         } else {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow + n) = v;
@@ -679,8 +680,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_f16_kernel(GemmParams p) {
 #pragma unroll
                     for (int jj = 0; jj < TNv; ++jj) {
                         const f32x4 v = acc[i][jj] + bias4[jj];
-                        f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        if constexpr (EPI == EPI_F16_GELU) hv = gelu_h4(hv);
+                        f16x4 hv;
+                        if constexpr (EPI == EPI_F16_GELU) hv = gelu_f16x4(v);
+                        else hv = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                         const int ch = (jj * 2 + (g >> 1)) ^ (row & 7);
                         *reinterpret_cast<f16x4*>(scr + row * 64 + ch * 8 + (g & 1) * 4) = hv;
                     }

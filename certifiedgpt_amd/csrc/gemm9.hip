@@ -1,5 +1,5 @@
 // gemm9.hip -- 256 x 256 x 64 fp16 MFMA GEMM: two 32-MFMA phases per K-tile, operand PARTS requested 1.5 K-tiles ahead by LDS-DMA
-// behind counted vmcnt waits, and (round 3) the GELU of the ViT MLP's fc1 moved out of the epilogue into the NEXT tile's K loop.
+// behind counted vmcnt waits.  The library's kernel for every large shape (M >= 1024, more than 128 tiles): all four ViT GEMMs.
 //
 // Tile, LDS image, swizzle, transposed accumulators, persistent XCD-aware tile walk, 192-column last tiles and LDS-transposed fp16
 // epilogue are those of gemm3_f16_kernel (gemm.hip); every kernel gives the same bits (tests/test_gpu_kernels.py).
@@ -289,8 +289,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #pragma unroll
                         for (int jj = 0; jj < TNv; ++jj) {
                             const f32x4 v = acc[i][jj] + bias4[jj];
-                            f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                            if constexpr (GELU) hv = gelu_h4(hv);
+                            f16x4 hv;
+                            if constexpr (GELU) hv = gelu_f16x4(v);
+                            else hv = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                             const int ch = (jj * 2 + (eg >> 1)) ^ (row & 7);
                             *reinterpret_cast<f16x4*>(scr + row * 64 + ch * 8 + (eg & 1) * 4) = hv;
                         }

@@ -56,22 +56,23 @@ __device__ __forceinline__ float gelu_erf(float x) {
     asm volatile("" : "+v"(r));                          // the fp32 result is materialised before any conversion
     return r;
 }
-// What every EPI_F16_GELU path computes: nn.GELU applied to the fp16 tensor `fc1` produces under autocast (eva_vit.py:59-61 with
-// base_model.py:141-142) -- fp32 arithmetic on the fp16-ROUNDED linear output, result rounded to fp16.  Going through the fp16 value
-// is what lets gemm9.hip write it out and finish GELU later (deferred GELU) with the same bits as the fused epilogues.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f16x4 gelu_h4(f16x4 h) {
-    f32x2 a = gelu_erf2(f32x2{(float)h[0], (float)h[1]}), b = gelu_erf2(f32x2{(float)h[2], (float)h[3]});
+// Every EPI_F16_GELU path evaluates GELU on the fp32 value acc + bias (the reference's autocast rounds the linear output to fp16 first,
+// eva_vit.py:59-61 with base_model.py:141-142: this is at least as precise) and converts the fp32 result to fp16 -- the same
+// arithmetic in every kernel and tile path, so a value depends on nothing but the element (tests/test_gpu_kernels.py).  Rounding
+// through fp16 first (tried in round 3 for a deferred GELU, profiles/r03/gemm_deferred_gelu.txt) costs one more VALU instruction per
+// value in an epilogue that is VALU-bound.
+__device__ __forceinline__ f16x4 gelu_f16x4(f32x4 v) {
+    f32x2 a = gelu_erf2(f32x2{v[0], v[1]}), b = gelu_erf2(f32x2{v[2], v[3]});
     asm volatile("" : "+v"(a), "+v"(b));                 // fp32 results materialised before the conversions (no fused fma + cvt)
     return f16x4{(half_t)a[0], (half_t)a[1], (half_t)b[0], (half_t)b[1]};
 }
-__device__ __forceinline__ half_t gelu_h(float v) { return (half_t)gelu_erf((float)(half_t)v); }
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float v) {
     if constexpr (EPI == EPI_F16) {
         reinterpret_cast<half_t*>(p.out)[(int64_t)m * p.ldo + n] = (half_t)v;
     } else if constexpr (EPI == EPI_F16_GELU) {
-        reinterpret_cast<half_t*>(p.out)[(int64_t)m * p.ldo + n] = gelu_h(v);
+        reinterpret_cast<half_t*>(p.out)[(int64_t)m * p.ldo + n] = (half_t)gelu_erf(v);
     } else if constexpr (EPI == EPI_F32) {
         reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + n] = v;
     } else if constexpr (EPI == EPI_RESID) {
@@ -131,8 +132,9 @@ __device__ __forceinline__ void gemm_epilogue_256(const GemmParams& p, f32x4 (&a
         }
         if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n);
         if constexpr (EPI == EPI_F16 || EPI == EPI_F16_GELU) {
-            f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            if constexpr (EPI == EPI_F16_GELU) hv = gelu_h4(hv);
+            f16x4 hv;
+            if constexpr (EPI == EPI_F16_GELU) hv = gelu_f16x4(v);
+            else hv = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             *reinterpret_cast<f16x4*>(reinterpret_cast<half_t*>(p.out) + orow + n) = hv;
         } else {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow + n) = v;
