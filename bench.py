@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--n", type=int, default=N)      # BASELINE configs[3]: --n 1000 (sharded 125 / GPU at 8 GPUs)
     ap.add_argument("--n0", type=int, default=N0)
     ap.add_argument("--decode", choices=["graph", "hf"], default="graph")   # --workload minigpt4: greedy decode as one hipGraph | HF generate
+    ap.add_argument("--prefill-linear", choices=["cgpt", "torch"], default="cgpt")   # graph decode: the prefill's linears through this library's GEMM
     args = ap.parse_args()
     headline = args.workload == "vit_head" and args.img_size == 224 and args.n == N and args.n0 == N0
     n_est, n_sel = args.n, args.n0
@@ -237,7 +238,7 @@ def main():
         emb = clf.encode_img_noisy(images[0], 0, per_gpu, SIGMA, 42)
         vocab = sorted(set(probe.generate_from_embeds(emb, prompt)))[:NUM_CLASSES - 1]
         base = MiniGPT4Classifier(clf, llm, tok, prompt, AnswerLabelMap(NUM_CLASSES, vocab, frozen=True), max_new_tokens=20, max_batch=per_gpu,
-                                  decode=args.decode)
+                                  decode=args.decode, prefill_linear=args.prefill_linear)
     smooth = cg.Smooth(base, NUM_CLASSES, SIGMA, seed=42, non_certifiable=(base.label_map.other_id,) if gen else ())
     torch.cuda.synchronize()
 
@@ -361,14 +362,22 @@ def main():
         embs = torch.cat([segs[0].expand(per_gpu, -1, -1), emb.to(segs[0].dtype), segs[1].expand(per_gpu, -1, -1)], dim=1)
         hf = MiniGPT4Classifier(clf, llm, tok, prompt, base.label_map, max_new_tokens=20, max_batch=per_gpu, decode="hf")
         gr = MiniGPT4Classifier(clf, llm, tok, prompt, base.label_map, max_new_tokens=20, max_batch=per_gpu, decode="graph")
+        gc = MiniGPT4Classifier(clf, llm, tok, prompt, base.label_map, max_new_tokens=20, max_batch=per_gpu, decode="graph", prefill_linear="cgpt")
         hf_ms, a_hf = timed(lambda: hf.generate_from_embeds(emb, prompt), reps=2)
         gr_ms, a_gr = timed(lambda: gr.generate_from_embeds(emb, prompt), reps=2)
+        gc_ms, a_gc = timed(lambda: gc.generate_from_embeds(emb, prompt), reps=2)
+        from certifiedgpt_amd.minigpt4 import _LinearRoute
         with torch.no_grad():
             pre_ms, _ = timed(lambda: llm(inputs_embeds=embs, use_cache=True, logits_to_keep=1).logits, reps=2)
+            with _LinearRoute.enabled():
+                pre_c_ms, _ = timed(lambda: llm(inputs_embeds=embs, use_cache=True, logits_to_keep=1).logits, reps=2)
         gen_report = {"rows_per_batch": per_gpu, "prompt_tokens_incl_32_image_tokens": int(embs.shape[1]),
                       "encode_img_ms": enc_ms, "hf_generate_ms": hf_ms, "graph_decode_ms": gr_ms, "prefill_alone_ms": pre_ms,
                       "per_token_step_ms_hf": (hf_ms - pre_ms) / 19.0, "per_token_step_ms_graph": (gr_ms - pre_ms) / 19.0,
-                      "answers_identical_rows": sum(int(a == b) for a, b in zip(a_hf, a_gr)), "decode": args.decode,
+                      "graph_decode_cgpt_prefill_ms": gc_ms, "prefill_alone_cgpt_linears_ms": pre_c_ms, "routed_linears": gc.routed_linears,
+                      "answers_identical_rows": sum(int(a == b) for a, b in zip(a_hf, a_gr)),
+                      "answers_identical_rows_cgpt_prefill_vs_hf": sum(int(a == b) for a, b in zip(a_hf, a_gc)), "decode": args.decode,
+                      "prefill_linear": args.prefill_linear,
                       "decode_stats": base.decode_stats}
 
     if rank == 0:
@@ -412,7 +421,8 @@ def main():
             if gen:
                 what += (" over full MiniGPT-4: encode_img in HIP + random-init decoder of the Vicuna-7B architecture (fp16, greedy decode on "
                          "PyTorch-ROCm: %s; 20 new tokens per noisy copy, batches of %d), answers -> classes by a frozen vocabulary of %d "
-                         "answers (BASELINE configs[2])" % ("prefill + 19 steps replayed from one hipGraph" if args.decode == "graph" else
+                         "answers (BASELINE configs[2])" % (("prefill + 19 steps replayed from one hipGraph" + (", the prefill's linears through "
+                                                             "libcgpt's GEMM" if args.prefill_linear == "cgpt" else "")) if args.decode == "graph" else
                                                             "HF generate", per_gpu, len(base.label_map.answers)))
                 line["minigpt4_phases"] = gen_report
             line["config"]["workload"] = (f"NON-HEADLINE data point: mode={mode}, image {args.img_size}x{args.img_size} (T={T}), "

@@ -85,6 +85,62 @@ class WordHashTokenizer:
         return " ".join(out)
 
 
+class _LinearRoute:
+    """Routes the bias-free fp16 `nn.Linear` layers of a frozen decoder through libcgpt's MFMA GEMM (`cgpt_linear_f16`, the kernel
+    of the ViT's qkv / proj / MLP) for calls with at least `min_rows` rows, i.e. the PREFILL of a Monte-Carlo batch (200 rows x 44
+    tokens = 8 800 rows); decode steps (one row per copy) stay with the vendor library.  Only active inside `enabled()`, so a
+    module shared with an unpatched caller is untouched outside; one patch per module."""
+    active = False
+
+    @classmethod
+    def install(cls, model, min_rows=1024):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        n = 0
+        for m in model.modules():
+            if not isinstance(m, torch.nn.Linear):
+                continue
+            if getattr(m, "_cgpt_routed", False):                       # patched by an earlier classifier on the same module
+                n += 1
+                continue
+            w = m.weight
+            if (m.bias is not None or w.dtype != torch.float16 or not w.is_cuda or not w.is_contiguous()
+                    or m.in_features % 64 or m.out_features % 256):
+                continue                                                # W must be readable for whole 256-row tiles, K in 64s
+            orig = m.forward
+
+            def fwd(x, m=m, orig=orig):
+                rows = x.numel() // x.shape[-1]
+                if not cls.active or rows < min_rows or x.dtype != torch.float16 or not x.is_cuda:
+                    return orig(x)
+                K, N = m.in_features, m.out_features
+                a = x.new_empty(((rows + 255) // 256 * 256, K))         # the kernel reads whole 256-row tiles: rows past `rows` are
+                a[:rows].copy_(x.reshape(rows, K))                      # never stored from (their garbage stays in their own outputs)
+                out = x.new_empty((rows, N))
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                _lib.check(L.cgpt_linear_f16(C.c_void_p(a.data_ptr()), K, C.c_void_p(m.weight.data_ptr()), K, None,
+                                             C.c_void_p(out.data_ptr()), N, None, N, rows, N, K, 0, st))
+                return out.view(*x.shape[:-1], N)
+            m.forward = fwd
+            m._cgpt_routed = True
+            n += 1
+        return n
+
+    @classmethod
+    def enabled(cls):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, cls.active = cls.active, True
+            try:
+                yield
+            finally:
+                cls.active = old
+        return ctx()
+
+
 class MiniGPT4Classifier:
     """:param encoder: a `HipClassifier(mode="encode_img")` (or any object with `encode_img(images) -> (emb, atts)` and
                `encode_img_noisy(x, first_sample, num, sigma, seed) -> emb`, emb = [B, queries, llm_hidden])
@@ -96,7 +152,7 @@ class MiniGPT4Classifier:
     """
 
     def __init__(self, encoder, llama_model, llama_tokenizer, prompt, label_map, max_new_tokens=20, max_batch=None,
-                 generate_kwargs=None, decode="hf"):
+                 generate_kwargs=None, decode="hf", prefill_linear="torch"):
         self.encoder = encoder
         self.llama_model = llama_model
         self.llama_tokenizer = llama_tokenizer
@@ -114,8 +170,13 @@ class MiniGPT4Classifier:
         # decode = "graph": the same greedy decode -- the model's own forward for the prefill and for every step, a DynamicCache, EOS
         #   suppressed on the first token (min_length = 1), pad after EOS -- written as a fixed-length loop without host round trips and
         #   replayed from ONE hipGraph per (batch, prompt length); shared prompts on a HIP device only, everything else takes "hf".
-        assert decode in ("hf", "graph")
+        # prefill_linear = "cgpt" (with decode = "graph"): the decoder's bias-free fp16 linears run the prefill's rows through this
+        #   library's GEMM (see _LinearRoute); same arithmetic contract (fp16 operands, fp32 accumulation, fp16 result), other rounding
+        #   order than the vendor library.
+        assert decode in ("hf", "graph") and prefill_linear in ("torch", "cgpt")
         self.decode = decode
+        self.prefill_linear = prefill_linear
+        self.routed_linears = _LinearRoute.install(llama_model) if (decode == "graph" and prefill_linear == "cgpt") else 0
         self._graphs = {}
         self._eos_mask = None
         self.decode_stats = {"graph_replays": 0, "graph_captures": 0, "hf_calls": 0}
@@ -267,12 +328,15 @@ class MiniGPT4Classifier:
             static_in = embs.clone()
             side = torch.cuda.Stream(device=embs.device)
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                              # warm-up outside the capture (lazy initialisations)
-                self.greedy_tokens(static_in)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = self.greedy_tokens(static_in)
+            import contextlib
+            route = _LinearRoute.enabled() if self.routed_linears else contextlib.nullcontext()
+            with route:
+                with torch.cuda.stream(side):                          # warm-up outside the capture (lazy initialisations)
+                    self.greedy_tokens(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self.greedy_tokens(static_in)
             entry = (graph, static_in, static_out)
             self._graphs[key] = entry
             self.decode_stats["graph_captures"] += 1

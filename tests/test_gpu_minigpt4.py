@@ -150,3 +150,38 @@ def test_graph_decode_gives_the_answers_of_hf_generate(minigpt4):
         pair = s._sample_noise_pair(x0, 16, 24, 8)
         assert (pair[0].tolist(), pair[1].tolist()) == two
     assert outs[0] == outs[1] and outs[0][1] == answers
+
+
+def test_prefill_linears_through_the_library_gemm_match_torch():
+    """prefill_linear="cgpt": the decoder's bias-free fp16 linears run calls of >= 1024 rows through cgpt_linear_f16 (the ViT's MFMA GEMM)
+    inside the graph decode.  A 2-layer decoder with 256-aligned widths: the routed prefill's logits equal torch's to fp16 accumulation
+    noise, calls below the row threshold and callers outside `enabled()` are untouched, and the answers of a 64-row batch agree."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from certifiedgpt_amd.minigpt4 import _LinearRoute
+    cfg = LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, max_position_embeddings=256, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    torch.manual_seed(0)
+    llm = LlamaForCausalLM(cfg).to(device=DEV, dtype=torch.float16).eval()
+    assert _LinearRoute.install(llm, min_rows=1024) == 2 * 7 + 1           # q, k, v, o, gate, up, down per layer + lm_head
+    x = torch.randn(64, 20, 256, device=DEV, dtype=torch.float16) * 0.5     # 1 280 rows
+    with torch.no_grad():
+        ref = llm(inputs_embeds=x, logits_to_keep=1).logits.float()
+        assert torch.equal(llm(inputs_embeds=x, logits_to_keep=1).logits.float(), ref)           # not enabled: torch's path, same bits
+        with _LinearRoute.enabled():
+            got = llm(inputs_embeds=x, logits_to_keep=1).logits.float()
+            small = llm(inputs_embeds=x[:8], logits_to_keep=1).logits.float()                    # 160 rows: below the threshold
+        assert torch.equal(small, llm(inputs_embeds=x[:8], logits_to_keep=1).logits.float())
+    assert rel_err(got, ref) <= 5e-3, rel_err(got, ref)
+
+    class Enc:
+        max_batch = 64
+    from certifiedgpt_amd.minigpt4 import WordHashTokenizer
+    tok = WordHashTokenizer(512)
+    a = MiniGPT4Classifier(Enc(), llm, tok, PROMPT, AnswerLabelMap(4, ()), max_new_tokens=4, decode="graph")
+    b = MiniGPT4Classifier(Enc(), llm, tok, PROMPT, AnswerLabelMap(4, ()), max_new_tokens=4, decode="graph", prefill_linear="cgpt")
+    assert b.routed_linears == 15 and a.routed_linears == 0                # one patch per module, counted again; `a` never enables it
+    emb = torch.randn(64, 8, 256, device=DEV) * 0.5
+    ans_a, ans_b = a.generate_from_embeds(emb, PROMPT), b.generate_from_embeds(emb, PROMPT)
+    agree = sum(int(p == q) for p, q in zip(ans_a, ans_b))
+    print("answers equal on", agree, "of 64 rows")
+    assert agree >= 48
