@@ -143,7 +143,8 @@ def build_generating_classifier(encoder, gen_cfg, num_classes, tokenizer=None, l
     """Full MiniGPT-4 as the base classifier (BASELINE configs[2]): `encoder` (HipClassifier, mode encode_img) + a frozen
     causal LM on PyTorch-ROCm, loaded BY LOCAL PATH only (base_model.py:181-247 loads `llama_model` the same way; nothing is
     ever fetched), + the answer vocabulary that defines the classes.
-        gen_cfg: {llama_model: <local dir>, prompt: "... <ImageHere> ...", answers: [...], max_new_tokens: 20}"""
+        gen_cfg: {llama_model: <local dir>, prompt: "... <ImageHere> ...", answers: [...], max_new_tokens: 20,
+                  decode: "hf" | "graph", prefill_linear: "torch" | "cgpt"}   (decode / prefill_linear: see MiniGPT4Classifier)"""
     from ..minigpt4 import MiniGPT4Classifier, prepare_texts
     from .label_adapter import AnswerLabelMap
     if llama_model is None:
@@ -169,7 +170,8 @@ def build_generating_classifier(encoder, gen_cfg, num_classes, tokenizer=None, l
                          "or shorten the vocabulary -- truncating it would move real answers into the non-certifiable bucket")
     label_map = AnswerLabelMap(num_classes, answers, frozen=True)
     return MiniGPT4Classifier(encoder, llama_model, tokenizer, prompt, label_map,
-                              max_new_tokens=int(gen_cfg.get("max_new_tokens", 20)), max_batch=encoder.max_batch)
+                              max_new_tokens=int(gen_cfg.get("max_new_tokens", 20)), max_batch=encoder.max_batch,
+                              decode=gen_cfg.get("decode", "hf"), prefill_linear=gen_cfg.get("prefill_linear", "torch"))
 
 
 def build_classifier(model_cfg, num_classes, max_batch, device_index, tokenizer=None, llama_model=None):
