@@ -312,7 +312,7 @@ def main():
             traffic_note = ("bytes per launch of %s from %s, taken at commit %s (%s this run's libcgpt.so; rocprofv3 --pmc FETCH_SIZE / "
                             "WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted): read %.0f MB + "
                             "write %.0f MB vs algorithmic %.0f MB (A %.0f + W %.0f + out %.0f; full %d-sample batches)" % (
-                                pm["kernel_name"].split("(")[0][-40:], rel, meta.get("git_head"),
+                                FC1_KERNEL, rel, meta.get("git_head"),
                                 "the same build as" if same else "a DIFFERENT build than",
                                 pm["hbm_read_bytes_corrected"] / 1e6, pm["hbm_write_bytes"] / 1e6,
                                 (per_gpu * 257 * (1408 + 6144) * 2 + 6144 * 1408 * 2) / 1e6, per_gpu * 257 * 1408 * 2 / 1e6,
