@@ -282,6 +282,13 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             {
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
+                    // The two waves of a SIMD share its VALU by age: the older (early) half finishes its epilogue first and the younger
+                    // then runs the rest alone, at a single wave's issue rate (in-kernel stamps, fc1: 8.4 vs 11.4 us).  Priority for the
+                    // younger half during the FIRST two passes evens them out: fc1 -0.9 %, qkv -0.7 %, +0.35 % end to end (three
+                    // interleaved runs on one box; all four passes, one pass or three passes: neutral or worse;
+                    // profiles/r03/gemm_deferred_gelu.txt).
+                    if (ps == 0) { if (late) __builtin_amdgcn_s_setprio(1); }
+                    if (ps == 2) { if (late) __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii) {
                         const int i = ps * 2 + ii;
