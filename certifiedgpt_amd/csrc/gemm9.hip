@@ -155,6 +155,15 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #ifdef CGPT_STAMPS
     unsigned long long st_first = 0, st_loop = 0, st_epi = 0;
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+    // phase stamps of the K loop (cycles summed over all K-tiles): 0 L(P0) incl. its waits, 1 barrier, 2 M(P0), 3 barrier, 4 L(P1), 5 barrier,
+    // 6 M(P1), 7 barrier.  An s_memtime is issued in order: the M stamps are taken when the last MFMA has ISSUED, not completed.
+    unsigned long long ph9[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph_last = 0;
+#define CGPT9_PH_BEGIN ph_last = __builtin_amdgcn_s_memtime();
+#define CGPT9_PH(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph9[k] += tn_ - ph_last; ph_last = tn_; }
+#else
+#define CGPT9_PH_BEGIN
+#define CGPT9_PH(k)
 #endif
     auto tile_body = [&](auto tnv_tag, int tm, int ncol0) __attribute__((always_inline)) {
         constexpr int TNv = decltype(tnv_tag)::value;                       // column tiles of 16 per wave: 4, or 3 (192-column tile)
@@ -182,6 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             constexpr bool Z = decltype(zero_tag)::value != 0;
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             const half_t* st = smem9 + (c & 1) * STAGE;
+            CGPT9_PH_BEGIN
             // ---------------- P0 = (m0; n0, n1)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -202,7 +212,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             request(IntTag9<3>{});                                          // A(m1) of K-tile c+1
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wait_vm();                                                      // A(m1) of this K-tile has landed
+            CGPT9_PH(0)
             CGPT_SLOT_END
+            CGPT9_PH(1)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -217,7 +229,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < N1; ++j)
                         acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[i][2 + j], 0, 0, 0);
+            CGPT9_PH(2)
             CGPT_SLOT_END
+            CGPT9_PH(3)
             // ---------------- P1 = (m1; n1, n0)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -230,7 +244,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             request(IntTag9<2>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wait_vm();                                                      // A(m0), B(n0), B(n1) of K-tile c+1 have landed
+            CGPT9_PH(4)
             CGPT_SLOT_END
+            CGPT9_PH(5)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -245,7 +261,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[4 + i][j], 0, 0, 0);
+            CGPT9_PH(6)
             CGPT_SLOT_END
+            CGPT9_PH(7)
             ++c;
         };
 
@@ -346,6 +364,8 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     if (p.dbg && lane == 0) {
         unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
         d[0] = __builtin_amdgcn_s_memtime() - st_begin; d[1] = st_first; d[2] = st_loop; d[3] = st_epi;
+        unsigned long long* e = p.dbg + (size_t)gridDim.x * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8;   // second table: phase stamps
+        for (int k = 0; k < 8; ++k) e[k] = ph9[k];
     }
 #endif
 #undef CGPT_FENCE
