@@ -52,6 +52,9 @@ template <int DPAD> __device__ __forceinline__ int k_chunk_pos(int row, int ch) 
 }
 
 #define CGPT_FENCE __builtin_amdgcn_sched_barrier(0);
+#ifndef CGPT_ATT_PLAIN_WALK
+#define CGPT_ATT_PLAIN_WALK 0       // A/B builds: 1 = the round-robin (sample, head) walk of rounds 1-2
+#endif
 
 // HD: head_dim (88 | 64); DPAD: HD rounded up to 32; NKT: 16-key tiles held (keys padded to NKT*16); NT: threads.
 template <int HD, int DPAD, int NKT, int NT>
@@ -69,6 +72,16 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, g = lane >> 4;
     const int nitems = p.heads * p.B;
+    // Walk position -> (sample, head).  The 16 heads of a ViT sample are 176-byte column blocks of the same 8 448-byte qkv rows, so
+    // neighbouring heads share the 128-byte lines at their borders, and a head's rows are 2-3 lines of 176 useful bytes each: dealt
+    // round-robin, neighbouring heads land on DIFFERENT XCDs (workgroups b and b + 8 share one) and every XCD's L2 fetches those lines
+    // for itself -- 790 MB of reads per launch against 543 MB of Q + K + V (PMC, profiles/r03/pmc_summary.json).  With a grid that is a
+    // multiple of 8, XCD x = position % 8 takes the samples x, x + 8, ... and walks each one's heads on consecutive workgroups of its
+    // own, so a sample's lines are fetched once per launch.  (Speed only: any placement gives the same result.)
+    const bool xcd_walk = (gridDim.x & 7) == 0 && p.B >= 64 && !CGPT_ATT_PLAIN_WALK;   // (few samples: whole samples per XCD would not balance)
+    auto item_valid = [&](int it) { return xcd_walk ? ((it >> 3) / p.heads) * 8 + (it & 7) < p.B : it < nitems; };
+    auto item_b = [&](int it) { return xcd_walk ? ((it >> 3) / p.heads) * 8 + (it & 7) : it / p.heads; };
+    auto item_h = [&](int it) { return xcd_walk ? (it >> 3) % p.heads : it % p.heads; };
 
     // ---- staging registers: this thread's NV 16-byte pieces of K (or V) of one (sample, head) item.
     // Loads are UNCONDITIONAL from clamped addresses (a guarded load becomes its own basic block with a vmcnt wait at the
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
     // take half the registers of per-lane pointers, which the compiler used to spill: a scratch reload in front of a request
     // waits for EVERY load in flight, e.g. for the V loads issued just before the first QK^T)
     auto request_kv = [&](int item, bool want_v) {
-        const int hh = item % p.heads, bb = item / p.heads;
+        const int hh = item_h(item), bb = item_b(item);
         const half_t* G = (want_v ? p.V : p.K) + (int64_t)bb * p.kv_batch_stride + hh * HD;
         const int ldg = (int)p.ldk;
 #pragma unroll
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         }
     };
     auto request_q = [&](int qt) { request_q_from(Qb, qt); };
-    auto q_base_of = [&](int it) { return p.Q + (int64_t)(it / p.heads) * p.q_batch_stride + (it % p.heads) * HD; };
+    auto q_base_of = [&](int it) { return p.Q + (int64_t)item_b(it) * p.q_batch_stride + item_h(it) * HD; };
     auto take_q = [&]() {
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) qf[ds] = (ds * 32 + g * 8 < HD) ? qnext[ds] : zero8;
@@ -259,16 +272,16 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
 #endif
     // ---- persistent walk over (sample, head) items
     int item = blockIdx.x;
-    if (item < nitems) {
+    if (item_valid(item)) {
         request_kv(item, false);
         if (wave < nqt) request_q_from(q_base_of(item), wave);   // later items: requested at the end of the previous item
     }
-    for (; item < nitems; item += gridDim.x) {
+    for (; item_valid(item); item += gridDim.x) {
 #ifdef CGPT_STAMPS
         unsigned long long tlast = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-        const int h = item % p.heads, b = item / p.heads;
+        const int h = item_h(item), b = item_b(item);
         Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
         Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
         int qt = wave;
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         // first query tile of every wave: QK^T + softmax run before V is needed in LDS
         // after a wave has taken its LAST query tile of this item it requests its first tile of the NEXT item: a whole tile of
         // lead (issued at the top of the item the load sat exposed in front of the first QK^T: ~4k of that phase's ~10k cycles)
-        const bool more_items = item + (int)gridDim.x < nitems;
+        const bool more_items = item_valid(item + (int)gridDim.x);
         auto request_following = [&](int cur) {
             if (cur + NWAVES < nqt) request_q(cur + NWAVES);
             else if (more_items) request_q_from(q_base_of(item + gridDim.x), wave);
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         __syncthreads();
         CGPT_ASTAMP(2)                                   // V -> LDS (incl. waiting for its loads) + barrier
         // the staging registers are free: request the NEXT item's K now; it lands during the rest of this item
-        if (item + (int)gridDim.x < nitems) request_kv(item + gridDim.x, false);
+        if (more_items) request_kv(item + gridDim.x, false);
         if (have) pv_store(qt);
         CGPT_ASTAMP(3)                                   // first P.V + store
         for (qt += NWAVES; qt < nqt; qt += NWAVES) {
