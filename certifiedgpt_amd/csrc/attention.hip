@@ -416,13 +416,17 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
         }
     }
 
-    // XCD x owns the (sample, head) pairs x, x+8, ... and walks them pair-major (see above)
+    // XCD x owns the (sample, head) pairs x, x+8, ... and walks them pair-major (see above); with 64 samples or more it owns whole
+    // SAMPLES x, x+8, ... instead (pair q of its walk = sample 8 (q / heads) + x, head q % heads), so that the 128-byte lines which
+    // neighbouring heads of a sample share at their borders are fetched by one L2 (see attention_kernel's walk)
     const int npairs = p.heads * p.B;
     const bool xcd_map = (gridDim.x & 7) == 0;
+    const bool by_sample = xcd_map && p.B >= 64;
     const int xcd = xcd_map ? (int)(blockIdx.x & 7) : 0, nx = xcd_map ? 8 : 1;
     const int lid = xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, nl = xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-    const int my_pairs = (npairs - xcd + nx - 1) / nx;
+    const int my_pairs = by_sample ? ((p.B - xcd + 7) / 8) * p.heads : (npairs - xcd + nx - 1) / nx;
     const int nwork = my_pairs * nqb;
+    auto pair_of = [&](int q) { return by_sample ? ((q / p.heads) * 8 + xcd) * p.heads + q % p.heads : xcd + nx * q; };   // = sample * heads + head
 
     // request chunk c of work item w into buffer `buf`: request r = wave + 8 i of the chunk covers slots 64 r .. 64 r + 63 of
     // the buffer image (K slots first); a lane fetches the 16-byte chunk that belongs in ITS slot, pad slots are skipped.
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     const half_t *nKg = nullptr, *nVg = nullptr;
     auto set_next = [&](int w, int c) {
         nw = w; nc = c;
-        const int pair = xcd + nx * (w / nqb);
+        const int pair = pair_of(w / nqb);
         const int h = pair % p.heads, b = pair / p.heads;
         nKg = p.K + (int64_t)b * p.kv_batch_stride + h * HD;
         nVg = p.V + (int64_t)b * p.kv_batch_stride + h * HD;
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     // unit's softmax and P.V and the epilogue instead of in front of the item's first QK^T.
     f16x8 qf[2][NDS];
     auto load_q = [&](int wi) {
-        const int pair = xcd + nx * (wi / nqb), qb = wi % nqb;
+        const int pair = pair_of(wi / nqb), qb = wi % nqb;
         const half_t* Qb = p.Q + (int64_t)(pair / p.heads) * p.q_batch_stride + (pair % p.heads) * HD;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     for (int i = 0; i < NI; ++i) request_part(i, 0);
     int buf = 0;
     for (; w < nwork; w += nl) {
-        const int pair = xcd + nx * (w / nqb), qb = w % nqb;
+        const int pair = pair_of(w / nqb), qb = w % nqb;
         const int h = pair % p.heads, b = pair / p.heads;
         half_t* Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
         const int q0 = qb * 256 + wave * 32;                                // this wave's queries q0 .. q0 + 31 (tiles a, b)

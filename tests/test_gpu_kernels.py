@@ -137,6 +137,7 @@ def attn_ref(q, k, v, heads, hd, scale):
                                                # workgroups of one XCD); 67 and 130 samples leave the XCDs unequal shares, 130 x 16 and
                                                # 70 x 12 items are several per workgroup
                                                (67, 16, 88, 257, 257), (130, 16, 88, 40, 40), (70, 12, 64, 32, 257), (64, 3, 64, 8, 17),
+                                               (66, 4, 88, 300, 300), (65, 2, 64, 20, 500),   # ... and the streaming kernel's walk by samples
                                                # Tk > 288: K/V streamed through LDS in 192-key chunks (448^2 images, T = 1025)
                                                (2, 2, 88, 401, 401), (1, 16, 88, 1025, 1025), (2, 12, 64, 32, 1025),
                                                (1, 2, 88, 130, 300), (1, 2, 64, 289, 289), (1, 1, 88, 1, 577),
