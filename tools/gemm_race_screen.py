@@ -2,7 +2,8 @@
 (gemm_kernel 4): bitwise equality of the outputs over many launches -- fixed ViT / Q-Former shapes plus random shapes (ragged M, N
 not a multiple of 256 incl. the 192-column split, K from one K-tile up), all four epilogues, with competing traffic on a second
 stream every third launch (uneven timing).  A fragment read that overtakes its LDS-DMA request, or a request that overtakes a read,
-shows up as rare wrong tiles that a single clean run does not reveal.  Run on the GPU box:  python tools/gemm_race_screen.py [launches]"""
+shows up as rare wrong tiles that a single clean run does not reveal.  CGPT_SCREEN_KERNEL=16 screens another kernel (default 0 = the
+automatic choice).  Run on the GPU box:  python tools/gemm_race_screen.py [launches]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C, random, torch
@@ -12,6 +13,7 @@ L = cg.lib(); DEV = "cuda:0"
 def P(t): return C.c_void_p(t.data_ptr()) if t is not None else None
 def st(): return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 LAUNCHES = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+SCREEN = int(os.environ.get("CGPT_SCREEN_KERNEL", "0"))
 side = torch.cuda.Stream()
 ja = torch.randn(6144, 6144, device=DEV, dtype=torch.float16)
 shapes = [(65535, 1408, 6144, 0), (65535, 6144, 1408, 1), (40000, 3072, 1152, 1), (65535, 4224, 1408, 0), (65535, 1408, 1408, 0), (65535, 9216, 1408, 0),
@@ -43,10 +45,10 @@ for (M, N, K, epi) in shapes:
         if it % 3 == 1:
             with torch.cuda.stream(side):
                 ja @ ja
-        if not torch.equal(run(14), ref):
+        if not torch.equal(run(SCREEN), ref):
             nbad += 1
     torch.cuda.synchronize()
     print(f"{M}x{N}x{K} epi{epi}: {LAUNCHES - nbad}/{LAUNCHES} launches bit-identical to the phased kernel", flush=True)
     bad += nbad
 _lib.check(L.cgpt_set_option(b"gemm_kernel", 0))
-print(f"RACE SCREEN {'CLEAN' if bad == 0 else 'FAILED'}: {len(shapes)} shapes x {LAUNCHES} launches, {bad} mismatching launches")
+print(f"RACE SCREEN (gemm_kernel {SCREEN}) {'CLEAN' if bad == 0 else 'FAILED'}: {len(shapes)} shapes x {LAUNCHES} launches, {bad} mismatching launches")
