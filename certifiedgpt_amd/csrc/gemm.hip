@@ -788,8 +788,7 @@ hipError_t launch_gemm(int epilogue, const GemmParams& p_in, hipStream_t stream)
     const int force = vec_ok ? g_gemm_kernel : 1;   // 0 auto, 1 = 128x128 register-staged, 3 = 256x128 direct-to-LDS, 4 = 256x256 phased
     if (force == 3 && (p.N % 128) == 0) return launch_v2_epi<128>(epilogue, p, stream);
     if (force == 4) return launch_v3_epi<4>(epilogue, p, stream);
-    if (force == 14) return launch_v9_epi(epilogue, p, stream, false);
-    if (force == 16) return launch_v9_epi(epilogue, p, stream, true);
+    if (force == 14) return launch_v9_epi(epilogue, p, stream);
 #ifdef CGPT_LAB
     if (force == 2) return launch_v2_epi<256>(epilogue, p, stream);
     if (force == 5) return launch_v3_epi<2>(epilogue, p, stream);

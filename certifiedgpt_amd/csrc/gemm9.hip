@@ -21,6 +21,12 @@
 // The first K-tile of a tile multiplies into a ZERO accumulator operand instead of clearing 128 registers (round 3: -1.5 ... -2 % on the
 // K = 1408 shapes, raw harness).
 //
+// Round 4 (profiles/r04/gemm_kloop.txt): ablation builds (-DCGPT_ABL) put a K-tile at 2 628 cycles against 2 031 with neither requests nor
+// fragment reads (2 193 / 2 252 with one of them): the L segments are shorter than their partner's M segment in every build, the loss is what a
+// partner's LDS reads and LDS-DMA traffic cost the wave that issues the MFMAs.  Fragment reads UNDER the M segments (A(m1) and the next K-tile's
+// B read into registers as their last MFMA is issued, counted waits at the ends of the M segments; bit-identical, race screen clean) were 13 %
+// SLOWER on every shape: a ds_read_b128 between MFMAs costs the issuing wave ~19 cycles of matrix-pipe time.  Removed again.
+//
 // Tried and removed in round 3 (profiles/r03/gemm_deferred_gelu.txt):
 //  * finishing fc1's GELU inside the NEXT tile's K loop -- raw fp16 tile written by a plain epilogue, re-read in 1-KiB pieces by LDS-DMA into
 //    the idle epilogue scratch behind exactly re-counted waits, GELU in the M segments, stored back.  Bit-identical, but 1 215 us per launch
@@ -46,7 +52,7 @@ constexpr int kMaxDevices9 = 64;
 template <int V> struct IntTag9 { static constexpr int value = V; };
 
 
-template <int EPI, bool UM>
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     constexpr int BM2 = 256, BN_ = 256;
     constexpr int A_ELEMS = BM2 * BK, STAGE = 2 * A_ELEMS;                 // halfs: A image then W image, 128-byte rows
@@ -151,10 +157,8 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     }
     half_t* const scr = scratch_all + wave * 2048;                          // 4 KiB of epilogue scratch per wave
     float* const bias_lds = reinterpret_cast<float*>(scr);
-    // K-tile 0 of the first tile: A(m0), B(n0), B(n1) landed for every wave (the younger parts stay in flight, as in steady state);
-    // UM: all of K-tile 0 (its A(m1) is read under the first M(P0)), the six pieces of K-tile 1 stay in flight
+    // K-tile 0 of the first tile: A(m0), B(n0), B(n1) landed for every wave (the younger parts stay in flight, as in steady state)
     if (!req_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (UM) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     CGPT_SLOT_END
 
@@ -278,119 +282,11 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             ++c;
         };
 
-        // ---- UM: the same K-tile with the fragment reads of A(m1) and of the NEXT K-tile's B issued UNDER the M segments, into
-        // registers whose last MFMA has just been issued (M(P0) runs row-tile-major, M(P1) column-tile-major), so L(P0) keeps 8 reads
-        // and L(P1) none.  A part is read under an M segment only after EVERY wave has retired it one barrier earlier: the counted
-        // waits therefore sit at the END of the M segments --
-        //     end of M(P0)(c): vmcnt(2) retires A(m0), B(n0), B(n1) of c+1 (requested in L(P1)(c-1), 3.5 slots earlier; B is read under
-        //                      M(P1)(c) -- early half: two slots later, i.e. one barrier after the late half's wait)
-        //     end of M(P1)(c): vmcnt(6) retires A(m1) of c+1 (requested in L(P0)(c); read under M(P0)(c+1))
-        // and a part is re-requested at least one barrier after every wave's reads of it have returned (lgkmcnt(0) ends each L):
-        //     A(m1)(c+1) in L(P0)(c): its stage held A(m1)(c-1), read under M(P0)(c-1), returned by the end of L(P1)(c-1)
-        //     A(m0), B(c+2) in L(P1)(c): A(m0)(c) was read in L(P0)(c), B(c) under M(P1)(c-1) and returned by the end of L(P0)(c).
-        // Same MFMA chain per accumulator (k-step 0 then 1 of every K-tile): bit-identical to the classic body.
-        auto wait_vm_n = [&](auto n_tag) __attribute__((always_inline)) {
-            constexpr int NV = decltype(n_tag)::value;
-            if (!req_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if constexpr (NV == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        };
-        auto ktile_um = [&](auto first_tag, const bool last) __attribute__((always_inline)) {
-            constexpr bool Z = decltype(first_tag)::value != 0;              // first K-tile of the tile: zero accumulator operand, B read here
-#ifndef CGPT_UMX
-#define CGPT_UMX 0
-#endif
-            // experiment switches (timing only unless stated): 1 = A(m1) read in L(P1) (classic), 2 = B read in L(P0) (classic),
-            // 4 = counted waits back at the ends of the L segments (RACY with reads under M: timing only), 8 = one read per MFMA gap
-            constexpr int X = CGPT_UMX;
-            constexpr bool A1_UNDER_M = !(X & 1), B_UNDER_M = !(X & 2), WAIT_IN_L = (X & 4) != 0, SPREAD = (X & 8) != 0;
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            const half_t* st = smem9 + (c & 1) * STAGE;
-            const half_t* stn = smem9 + ((c + 1) & 1) * STAGE;
-            auto rd_a = [&](int i, int half, int ks) __attribute__((always_inline)) {
-                af[i][ks] = *reinterpret_cast<const f16x8*>(st + a_rd + (4 * half + i) * 16 * BK + (ks ? k_off1 : k_off0));
-            };
-            auto rd_b = [&](const half_t* stage, int j, int ks) __attribute__((always_inline)) {   // j = 0 .. TNv-1
-                const f16x8 v = *reinterpret_cast<const f16x8*>(stage + b_rd + j * 16 * BK + (ks ? k_off1 : k_off0));
-                if (j < 2) bf0[j][ks] = v; else bf1[j - 2][ks] = v;
-            };
-            auto bfrag = [&](int j, int ks) __attribute__((always_inline)) -> f16x8 { return j < 2 ? bf0[j][ks] : bf1[j - 2][ks]; };
-            // ---------------- L(P0): A(m0) [8]; request A(m1) of c+1
-            if constexpr (Z || !B_UNDER_M) {
-#pragma unroll
-                for (int j = 0; j < TNv; ++j) { rd_b(st, j, 0); rd_b(st, j, 1); }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { rd_a(i, 0, 0); rd_a(i, 0, 1); }
-            CGPT_FENCE
-            request(IntTag9<3>{});                                          // A(m1) of K-tile c+1
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (WAIT_IN_L) wait_vm();
-            CGPT_SLOT_END
-            // ---------------- M(P0) = (m0; n0, n1), row-tile-major; A(m1)[i] replaces A(m0)[i] as soon as its MFMAs are issued
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                    for (int j = 0; j < TNv; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfrag(j, ks), af[i][ks], (Z && ks == 0) ? zero4 : acc[i][j], 0, 0, 0);
-                        if constexpr (A1_UNDER_M && SPREAD) {                // the previous row tile's registers: one read per MFMA gap
-                            if (i > 0 && ks == 0 && j < 2) { CGPT_FENCE rd_a(i - 1, 1, j); CGPT_FENCE }
-                        }
-                    }
-                }
-                if constexpr (A1_UNDER_M && !SPREAD) { CGPT_FENCE rd_a(i, 1, 0); rd_a(i, 1, 1); CGPT_FENCE }
-            }
-            if constexpr (A1_UNDER_M && SPREAD) { CGPT_FENCE rd_a(3, 1, 0); rd_a(3, 1, 1); CGPT_FENCE }
-            if constexpr (!WAIT_IN_L) wait_vm_n(IntTag9<2>{});              // A(m0), B(n0), B(n1) of K-tile c+1 have landed
-            CGPT_SLOT_END
-            // ---------------- L(P1): no reads; request A(m0), B(n0), B(n1) of K-tile c+2
-            if constexpr (!A1_UNDER_M) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { rd_a(i, 1, 0); rd_a(i, 1, 1); }
-                CGPT_FENCE
-            }
-            request(IntTag9<0>{});
-            request(IntTag9<1>{});
-            request(IntTag9<2>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // A(m1) fragments (read under M(P0)) are back
-            if constexpr (WAIT_IN_L) wait_vm();
-            CGPT_SLOT_END
-            // ---------------- M(P1) = (m1; n0, n1), column-tile-major; B(c+1)[j] replaces B(c)[j] as soon as its MFMAs are issued
-#pragma unroll
-            for (int j = 0; j < TNv; ++j) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfrag(j, ks), af[i][ks], (Z && ks == 0) ? zero4 : acc[4 + i][j], 0, 0, 0);
-                        if constexpr (B_UNDER_M && SPREAD) {
-                            if (j > 0 && ks == 0 && i < 2 && !last) { CGPT_FENCE rd_b(stn, j - 1, i); CGPT_FENCE }
-                        }
-                    }
-                if constexpr (B_UNDER_M && !SPREAD) {
-                    CGPT_FENCE
-                    if (!last) { rd_b(stn, j, 0); rd_b(stn, j, 1); }
-                    CGPT_FENCE
-                }
-            }
-            if constexpr (B_UNDER_M && SPREAD) { CGPT_FENCE if (!last) { rd_b(stn, TNv - 1, 0); rd_b(stn, TNv - 1, 1); } CGPT_FENCE }
-            if constexpr (!WAIT_IN_L) wait_vm_n(IntTag9<6>{});              // A(m1) of K-tile c+1 has landed
-            CGPT_SLOT_END
-            ++c;
-        };
-
-        if constexpr (UM) {
-            ktile_um(IntTag9<1>{}, nk == 1);
-            for (int kt = 1; kt < nk; ++kt) ktile_um(IntTag9<0>{}, kt == nk - 1);
-        } else {
         ktile(IntTag9<1>{});
 #ifdef CGPT_STAMPS
         ts_k1 = __builtin_amdgcn_s_memtime();
 #endif
         for (int kt = 1; kt < nk; ++kt) ktile(IntTag9<0>{});
-        }
 
 #ifdef CGPT_STAMPS
         const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
@@ -491,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #undef CGPT_SLOT_END
 }
 
-template <int EPI, bool UM>
+template <int EPI>
 hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
     constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t) + 32768;   // two stages + epilogue scratch = 160 KiB
     int dev = 0;
@@ -500,7 +396,7 @@ hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
     static bool configured[kMaxDevices9] = {false};
     static int cus[kMaxDevices9] = {0};
     if (!configured[dev]) {
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm9_f16_kernel<EPI, UM>),
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm9_f16_kernel<EPI>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); e != hipSuccess) return e;
         int n = 0;
         if (hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
@@ -509,26 +405,21 @@ hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
     }
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = tiles < cus[dev] ? tiles : cus[dev];                   // one 512-thread workgroup per CU (LDS-limited), persistent
-    hipLaunchKernelGGL((gemm9_f16_kernel<EPI, UM>), dim3(grid), dim3(512), lds_bytes, stream, p);
+    hipLaunchKernelGGL((gemm9_f16_kernel<EPI>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
-}
-
-template <bool UM>
-hipError_t launch_v9_um(int epilogue, const GemmParams& p, hipStream_t stream) {
-    switch (epilogue) {
-        case EPI_F16: return launch_v9<EPI_F16, UM>(p, stream);
-        case EPI_F16_GELU: return launch_v9<EPI_F16_GELU, UM>(p, stream);
-        case EPI_F32: return launch_v9<EPI_F32, UM>(p, stream);
-        case EPI_RESID: return launch_v9<EPI_RESID, UM>(p, stream);
-        case EPI_PATCH: return launch_v9<EPI_PATCH, UM>(p, stream);
-        default: return hipErrorInvalidValue;
-    }
 }
 
 }  // namespace
 
-hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream, bool under_m) {
-    return under_m ? launch_v9_um<true>(epilogue, p, stream) : launch_v9_um<false>(epilogue, p, stream);
+hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream) {
+    switch (epilogue) {
+        case EPI_F16: return launch_v9<EPI_F16>(p, stream);
+        case EPI_F16_GELU: return launch_v9<EPI_F16_GELU>(p, stream);
+        case EPI_F32: return launch_v9<EPI_F32>(p, stream);
+        case EPI_RESID: return launch_v9<EPI_RESID>(p, stream);
+        case EPI_PATCH: return launch_v9<EPI_PATCH>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace cgpt

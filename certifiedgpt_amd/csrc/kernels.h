@@ -32,7 +32,7 @@ struct GemmParams {
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
 // gemm9.hip: 256x256 tile, two 32-MFMA phases per K-tile, operand parts requested 1.5 K-tiles ahead by LDS-DMA
-hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream, bool under_m = false);   // under_m: fragment reads of A(m1) / next B under the M segments
+hipError_t launch_v9_epi(int epilogue, const GemmParams& p, hipStream_t stream);
 #ifdef CGPT_LAB
 hipError_t launch_v6_epi(int epilogue, int mode, const GemmParams& p, hipStream_t stream);   // lab/gemm6.hip: 4-wave 128x128 wave tiles
 hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);             // lab/gemm8.hip: two 4-wave workgroups per CU, 128x256 tiles
@@ -40,7 +40,7 @@ hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);
 extern int g_gemm_ablate;
 extern int g_gemm_group_m;
 extern unsigned long long* g_gemm_dbg;
-extern int g_gemm_kernel;   // kernel override (speed only): 0 auto, 1 = 128x128, 3 = 256x128, 4 = 256x256 phased, 14 = 256x256 two-phase quadrant, 16 = the same with fragment reads under the M segments; lab builds: 2, 5..11, 15
+extern int g_gemm_kernel;   // kernel override (speed only): 0 auto, 1 = 128x128, 3 = 256x128, 4 = 256x256 phased, 14 = 256x256 two-phase quadrant; lab builds: 2, 5..11, 15
 
 // ---------------------------------------------------------------------------------------- attention
 // O[b,q,h*hd + d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d]   (eva_vit.py:133-150,

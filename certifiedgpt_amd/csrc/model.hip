@@ -769,11 +769,11 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
     const std::string k(key);
     if (k == "gemm_kernel") {
 #ifdef CGPT_LAB
-        const bool ok = value >= 0 && value <= 16;
+        const bool ok = value >= 0 && value <= 15;
 #else
-        const bool ok = value == 0 || value == 1 || value == 3 || value == 4 || value == 14 || value == 16;
+        const bool ok = value == 0 || value == 1 || value == 3 || value == 4 || value == 14;
 #endif
-        if (!ok) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_kernel must be 0, 1, 3, 4, 14 or 16");
+        if (!ok) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_kernel must be 0, 1, 3, 4 or 14");
         g_gemm_kernel = value;
         return CGPT_OK;
     }

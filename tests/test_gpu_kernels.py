@@ -22,7 +22,7 @@ def _gemm_kernels():
     L = cg.lib()
     lab = L.cgpt_set_option(b"gemm_kernel", 12) == 0
     L.cgpt_set_option(b"gemm_kernel", 0)
-    return [k for k in range(17) if k not in (13, 15)] if lab else [0, 1, 3, 4, 14, 16]
+    return [k for k in range(15) if k != 13] if lab else [0, 1, 3, 4, 14]
 
 
 GEMM_KERNELS = _gemm_kernels()
@@ -353,7 +353,6 @@ def test_two_phase_quadrant_kernel_is_bit_identical_to_the_phased_kernel(M, N, K
                 with torch.cuda.stream(side):
                     ja @ ja
             assert torch.equal(run(14), ref), it
-            assert torch.equal(run(16), ref), ("under-M reads", it)
     finally:
         _lib.check(L.cgpt_set_option(b"gemm_kernel", 0))
     torch.cuda.synchronize()
@@ -410,9 +409,8 @@ def test_gelu_epilogue_gives_the_same_bits_on_every_kernel_under_load(M, N, K):
             if it & 1:
                 with torch.cuda.stream(side):
                     ja @ ja
-            for kern in (14, 16):
-                got = run(kern)
-                assert torch.equal(got, ref), (kern, it, int((got != ref).sum()))
+            got = run(14)
+            assert torch.equal(got, ref), (it, int((got != ref).sum()))
     finally:
         _lib.check(L.cgpt_set_option(b"gemm_kernel", 0))
     torch.cuda.synchronize()
