@@ -269,18 +269,42 @@ def main():
     torch.cuda.synchronize()
     clf.profile_read(0)
     clf.profile(True)
+    if world > 1:
+        smooth.collect_timing(True)                  # HIP events around each rank's classifier pass and around the all-reduce
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     results += run(args.warmup, args.warmup + args.steps)
     torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0                 # this rank's own time, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     clf.profile(False)
+    ranks_report = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what the line needs to explain itself: per rank, the time in its own classifier passes, in the collective, and in total;
+        # and how many ranks the communicator really summed over (a SUM of ones through the same backend as the vote counts)
+        tm = smooth.timing()
+        smooth.collect_timing(False)
+        mine = torch.tensor([1e3 * t_rank, tm["compute_ms"], tm["allreduce_ms"], tm["allreduce_host_ms"], float(tm["calls"])],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ones = torch.ones(1, device=dev, dtype=torch.int64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rows = [[float(v) for v in r.tolist()] for r in allr]
+        ranks_report = {"summed_ranks": int(ones.item()),
+                        "per_rank_ms": [{"rank": i, "total": r[0], "classifier_passes": r[1], "all_reduce_device": r[2],
+                                         "all_reduce_host": r[3], "sample_noise_calls": int(r[4])} for i, r in enumerate(rows)],
+                        "rank_total_ms_max": max(r[0] for r in rows), "rank_total_ms_min": min(r[0] for r in rows),
+                        "classifier_ms_max": max(r[1] for r in rows), "classifier_ms_min": min(r[1] for r in rows),
+                        "all_reduce_device_ms_max": max(r[2] for r in rows),
+                        "note": "per rank over the timed region: HIP events around its own classifier passes and around dist.all_reduce of the "
+                                "vote histograms (device time: includes waiting for the slowest rank), host time inside dist.all_reduce; "
+                                "summed_ranks = SUM of ones through the same communicator"}
 
     # HBM-side traffic of the fc1 GEMM: rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled as the
     # MI355X guide prescribes for gfx950) cannot be collected from inside this process; the committed summary of the same
@@ -366,7 +390,18 @@ def main():
         hf_ms, a_hf = timed(lambda: hf.generate_from_embeds(emb, prompt), reps=2)
         gr_ms, a_gr = timed(lambda: gr.generate_from_embeds(emb, prompt), reps=2)
         gc_ms, a_gc = timed(lambda: gc.generate_from_embeds(emb, prompt), reps=2)
-        from certifiedgpt_amd.minigpt4 import _LinearRoute
+        from certifiedgpt_amd.minigpt4 import _LinearRoute, greedy_decode_parity, fp16_ulp
+        # parity of the measured path with the reference's call, row by row: HF generate's tokens and processed scores on this batch;
+        # a row may leave HF's trajectory only at a step whose HF top-2 margin is within the logit noise of the paths (eps = 4 fp16 ulp
+        # of the largest logit; tests/test_gpu_fullsize.py measures the noise itself): every DECISIVE row must give the identical answer
+        with torch.no_grad():
+            ho = llm.generate(inputs_embeds=embs, attention_mask=torch.ones(embs.shape[:2], dtype=torch.int, device=dev),
+                              max_new_tokens=20, output_scores=True, return_dict_in_generate=True, **base.generate_kwargs)
+            h_tok, h_sc = ho.sequences, torch.stack(ho.scores, dim=1).float()
+            eps = 4.0 * fp16_ulp(float(h_sc[torch.isfinite(h_sc)].abs().max()))
+            par_gr = greedy_decode_parity(h_tok, h_sc, gr._generate_graph(embs), eps)
+            par_gc = greedy_decode_parity(h_tok, h_sc, gc._generate_graph(embs), eps)
+            del ho, h_sc
         with torch.no_grad():
             pre_ms, _ = timed(lambda: llm(inputs_embeds=embs, use_cache=True, logits_to_keep=1).logits, reps=2)
             with _LinearRoute.enabled():
@@ -376,7 +411,13 @@ def main():
                       "per_token_step_ms_hf": (hf_ms - pre_ms) / 19.0, "per_token_step_ms_graph": (gr_ms - pre_ms) / 19.0,
                       "graph_decode_cgpt_prefill_ms": gc_ms, "prefill_alone_cgpt_linears_ms": pre_c_ms, "routed_linears": gc.routed_linears,
                       "answers_identical_rows": sum(int(a == b) for a, b in zip(a_hf, a_gr)),
-                      "answers_identical_rows_cgpt_prefill_vs_hf": sum(int(a == b) for a, b in zip(a_hf, a_gc)), "decode": args.decode,
+                      "answers_identical_rows_cgpt_prefill_vs_hf": sum(int(a == b) for a, b in zip(a_hf, a_gc)),
+                      "answers_identical_decisive": {"eps_logit": eps, "graph": f"{par_gr['decisive_identical']}/{par_gr['decisive']}",
+                                                     "graph_cgpt_prefill": f"{par_gc['decisive_identical']}/{par_gc['decisive']}",
+                                                     "rows_leaving_hf_at_a_decisive_step": len(par_gr["violations"]) + len(par_gc["violations"]),
+                                                     "note": "decisive = every step's HF top-2 logit margin > eps; other rows may flip on fp16 "
+                                                             "rounding of near-tied logits (random-init decoder)"},
+                      "decode": args.decode,
                       "prefill_linear": args.prefill_linear,
                       "decode_stats": base.decode_stats}
 
@@ -386,7 +427,8 @@ def main():
         all_tflops = all_flops / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
         line = {
             "metric": "certified images/sec (N=100, sigma=0.5)", "value": value, "unit": "certified images/s",
-            "n_gpus": world, "rccl_ranks": world if backend == "nccl" else (0 if world > 1 else 1),
+            "n_gpus": world,
+            "rccl_ranks": (ranks_report["summed_ranks"] if backend == "nccl" else 0) if world > 1 else 1,
             "collective_backend": backend or "none (single rank)",
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
@@ -414,6 +456,8 @@ def main():
             "single_image_certify_note": "one reference-shaped Smooth.certify(x, n0, n, alpha, batch_size=n0+n) per image, no grouping "
                                          "of images (the headline value sends groups of images through Smooth.certify_many)",
         }
+        if ranks_report is not None:
+            line["ranks"] = ranks_report
         if not headline:
             T = (args.img_size // 14) ** 2 + 1
             what = (f"8-step RGF attack (1 direction per step) + smoothed predict, {attack.forwards_per_image(n_est)} forwards per image"

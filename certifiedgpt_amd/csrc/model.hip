@@ -722,13 +722,18 @@ static int collect_rccl(struct dl_phdr_info* info, size_t, void* data) {
     return 0;
 }
 
+static cgpt_status allreduce_counts_call(const char* who, void* nccl_allreduce, void* rccl_comm, int64_t* counts_dev, int64_t count,
+                                         void* stream) {
+    const int rc = ((cgpt_nccl_allreduce_fn)nccl_allreduce)(counts_dev, counts_dev, (size_t)count, /*ncclInt64*/ 4, /*ncclSum*/ 0,
+                                                            rccl_comm, (hipStream_t)stream);
+    if (rc != 0) return cgpt_fail(CGPT_ERR_HIP, std::string(who) + ": ncclAllReduce returned " + std::to_string(rc));
+    return CGPT_OK;
+}
+
 cgpt_status cgpt_allreduce_counts_fn(void* nccl_allreduce, void* rccl_comm, int64_t* counts_dev, int64_t count, void* stream) {
     if (!nccl_allreduce || !rccl_comm || !counts_dev || count < 1)
         return cgpt_fail(CGPT_ERR_INVALID, "cgpt_allreduce_counts_fn: bad argument");
-    const int rc = ((cgpt_nccl_allreduce_fn)nccl_allreduce)(counts_dev, counts_dev, (size_t)count, /*ncclInt64*/ 4, /*ncclSum*/ 0,
-                                                            rccl_comm, (hipStream_t)stream);
-    if (rc != 0) return cgpt_fail(CGPT_ERR_HIP, "cgpt_allreduce_counts: ncclAllReduce returned " + std::to_string(rc));
-    return CGPT_OK;
+    return allreduce_counts_call("cgpt_allreduce_counts_fn", nccl_allreduce, rccl_comm, counts_dev, count, stream);
 }
 
 cgpt_status cgpt_allreduce_counts(void* rccl_comm, int64_t* counts_dev, int64_t count, void* stream) {
@@ -746,7 +751,7 @@ cgpt_status cgpt_allreduce_counts(void* rccl_comm, int64_t* counts_dev, int64_t 
     void* fn = lib ? dlsym(lib, "ncclAllReduce") : nullptr;
     if (lib) dlclose(lib);                                                   // drops only the reference RTLD_NOLOAD took
     if (!fn) return cgpt_fail(CGPT_ERR_STATE, "cgpt_allreduce_counts: " + mapped[0] + " is mapped but its ncclAllReduce cannot be reached");
-    return cgpt_allreduce_counts_fn(fn, rccl_comm, counts_dev, count, stream);
+    return allreduce_counts_call("cgpt_allreduce_counts", fn, rccl_comm, counts_dev, count, stream);
 }
 
 cgpt_status cgpt_certify_device(const int64_t* counts_selection_dev, const int64_t* counts_estimation_dev, int32_t num_classes,

@@ -85,12 +85,49 @@ class WordHashTokenizer:
         return " ".join(out)
 
 
+def greedy_decode_parity(hf_tokens, hf_scores, tokens, eps):
+    """Compare a greedy decode `tokens` [B, n] with HF `generate`'s `hf_tokens` [B, <= n] row by row, given HF's per-step processed
+    scores `hf_scores` [B, steps, V] (fp32).  Two greedy decoders of the SAME fp16 model can only part ways at a step where HF's own
+    top-2 margin is within the logit noise of the two paths (another GEMM / attention kernel rounds the fp16 logits differently), after
+    which the contexts differ and nothing more can be said about that row.  Returns a dict: `identical` rows, `decisive` rows (every
+    step's margin > eps: these MUST be identical), `violations` = rows whose first divergence sits at a step with margin > eps."""
+    B = hf_tokens.shape[0]
+    S = min(hf_tokens.shape[1], tokens.shape[1], hf_scores.shape[1])
+    top2 = hf_scores[:, :S].float().topk(2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]                                  # [B, S]; inf where only one candidate is finite
+    margin = torch.nan_to_num(margin, nan=float("inf"))
+    neq = tokens[:, :S] != hf_tokens[:, :S]
+    diverged = neq.any(dim=1)
+    first = torch.where(diverged, neq.float().argmax(dim=1), torch.zeros(B, dtype=torch.long, device=neq.device))
+    m_at = margin.gather(1, first[:, None])[:, 0]
+    violations = (diverged & (m_at > eps)).nonzero().flatten().tolist()
+    decisive = (margin > eps).all(dim=1)
+    return {"identical": int((~diverged).sum()), "diverged": int(diverged.sum()), "decisive": int(decisive.sum()),
+            "decisive_identical": int((decisive & ~diverged).sum()), "violations": violations,
+            "max_margin_at_divergence": float(m_at[diverged].max()) if bool(diverged.any()) else 0.0}
+
+
+def fp16_ulp(x):
+    """Spacing of fp16 at magnitude x (normal range)."""
+    import math
+    return 2.0 ** (math.floor(math.log2(max(float(x), 6.2e-5))) - 10)
+
+
 class _LinearRoute:
     """Routes the bias-free fp16 `nn.Linear` layers of a frozen decoder through libcgpt's MFMA GEMM (`cgpt_linear_f16`, the kernel
     of the ViT's qkv / proj / MLP) for calls with at least `min_rows` rows, i.e. the PREFILL of a Monte-Carlo batch (200 rows x 44
-    tokens = 8 800 rows); decode steps (one row per copy) stay with the vendor library.  Only active inside `enabled()`, so a
-    module shared with an unpatched caller is untouched outside; one patch per module."""
-    active = False
+    tokens = 8 800 rows); decode steps (one row per copy) stay with the vendor library.  One patch per module; the patch is inert
+    outside `enabled()`, and the switch is a context variable (per thread / per task), so another thread or another classifier that
+    calls the same shared decoder meanwhile is not routed.  Eligibility (fp16, contiguous, on the device, no bias, K in 64s, N in 256s)
+    is re-checked at every call: after a `.to()`, a dtype change or a weight swap (a LoRA merge) the original forward runs."""
+    import contextvars as _cv
+    _active = _cv.ContextVar("cgpt_linear_route", default=False)
+
+    @staticmethod
+    def _eligible(m):
+        w = m.weight
+        return (m.bias is None and w.dtype == torch.float16 and w.is_cuda and w.is_contiguous()
+                and w.shape == (m.out_features, m.in_features) and m.in_features % 64 == 0 and m.out_features % 256 == 0)
 
     @classmethod
     def install(cls, model, min_rows=1024):
@@ -104,19 +141,21 @@ class _LinearRoute:
             if getattr(m, "_cgpt_routed", False):                       # patched by an earlier classifier on the same module
                 n += 1
                 continue
-            w = m.weight
-            if (m.bias is not None or w.dtype != torch.float16 or not w.is_cuda or not w.is_contiguous()
-                    or m.in_features % 64 or m.out_features % 256):
-                continue                                                # W must be readable for whole 256-row tiles, K in 64s
+            if not cls._eligible(m):                                    # W must be readable for whole 256-row tiles, K in 64s
+                continue
             orig = m.forward
 
             def fwd(x, m=m, orig=orig):
-                rows = x.numel() // x.shape[-1]
-                if not cls.active or rows < min_rows or x.dtype != torch.float16 or not x.is_cuda:
+                rows = x.numel() // x.shape[-1] if x.shape[-1] else 0
+                if (not cls._active.get() or rows < min_rows or x.dtype != torch.float16 or not x.is_cuda
+                        or x.device != m.weight.device or not cls._eligible(m)):
                     return orig(x)
                 K, N = m.in_features, m.out_features
-                a = x.new_empty(((rows + 255) // 256 * 256, K))         # the kernel reads whole 256-row tiles: rows past `rows` are
-                a[:rows].copy_(x.reshape(rows, K))                      # never stored from (their garbage stays in their own outputs)
+                a = x.reshape(rows, K)
+                if rows % 256 or not a.is_contiguous():                 # the kernel reads whole 256-row tiles: pad rows exist but are
+                    pad = x.new_empty(((rows + 255) // 256 * 256, K))   # never stored from (their garbage stays in their own outputs)
+                    pad[:rows].copy_(a)
+                    a = pad
                 out = x.new_empty((rows, N))
                 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
                 _lib.check(L.cgpt_linear_f16(C.c_void_p(a.data_ptr()), K, C.c_void_p(m.weight.data_ptr()), K, None,
@@ -133,11 +172,11 @@ class _LinearRoute:
 
         @contextlib.contextmanager
         def ctx():
-            old, cls.active = cls.active, True
+            token = cls._active.set(True)
             try:
                 yield
             finally:
-                cls.active = old
+                cls._active.reset(token)
         return ctx()
 
 
@@ -168,18 +207,25 @@ class MiniGPT4Classifier:
         self.last_answers = []
         # decode = "hf": `llama_model.generate(...)` exactly as the reference calls it (minigpt_base.py:418-431).
         # decode = "graph": the same greedy decode -- the model's own forward for the prefill and for every step, a DynamicCache, EOS
-        #   suppressed on the first token (min_length = 1), pad after EOS -- written as a fixed-length loop without host round trips and
+        #   suppressed on the first token where the installed `generate` does so (min_length = 1: _hf_min_length), pad after EOS -- written as a fixed-length loop without host round trips and
         #   replayed from ONE hipGraph per (batch, prompt length); shared prompts on a HIP device only, everything else takes "hf".
+        #   Parity with HF generate (tests/test_gpu_fullsize.py, Vicuna-7B widths, 200 rows x 20 tokens): run eagerly the loop gives HF's
+        #   tokens and logits bit for bit; under graph capture other vendor kernels get picked, so logits move by fp16 rounding and a row
+        #   may leave HF's trajectory at a step where HF's own top-2 margin is within that noise (near-tied logits of a random-init
+        #   decoder) -- every decisive row gives the identical answer.
         # prefill_linear = "cgpt" (with decode = "graph"): the decoder's bias-free fp16 linears run the prefill's rows through this
         #   library's GEMM (see _LinearRoute); same arithmetic contract (fp16 operands, fp32 accumulation, fp16 result), other rounding
-        #   order than the vendor library.
+        #   order than the vendor library: first-token logits within 4 fp16 ulp, same decisive-row rule.
         assert decode in ("hf", "graph") and prefill_linear in ("torch", "cgpt")
         self.decode = decode
         self.prefill_linear = prefill_linear
         self.routed_linears = _LinearRoute.install(llama_model) if (decode == "graph" and prefill_linear == "cgpt") else 0
-        self._graphs = {}
+        import collections
+        self._graphs = collections.OrderedDict()            # LRU of captured decode graphs, see _generate_graph
+        self.max_graphs = 4
         self._eos_mask = None
-        self.decode_stats = {"graph_replays": 0, "graph_captures": 0, "hf_calls": 0}
+        self._min_length_minus_prompt = None                # see _hf_min_length
+        self.decode_stats = {"graph_replays": 0, "graph_captures": 0, "graph_evictions": 0, "hf_calls": 0, "hf_fallback_kwargs": 0}
 
     # ---- nn.Module-shaped surface used by Smooth (smoothing.py:42,71)
     def eval(self):
@@ -236,6 +282,8 @@ class MiniGPT4Classifier:
             outputs = self._generate_graph(embs)
         else:
             self.decode_stats["hf_calls"] += 1
+            if self.decode == "graph" and shared and embs.is_cuda:
+                self.decode_stats["hf_fallback_kwargs"] += 1            # generation arguments outside the greedy whitelist
             outputs = self.llama_model.generate(inputs_embeds=embs, attention_mask=attn_mask, max_new_tokens=self.max_new_tokens,
                                                 **self.generate_kwargs)
         return self._decode_outputs(outputs)
@@ -250,12 +298,40 @@ class MiniGPT4Classifier:
         return answers
 
     # ---- greedy decode without host round trips (decode = "graph")
-    def _greedy_defaults(self):
-        k = self.generate_kwargs
-        return (k.get("num_beams", 1) == 1 and not k.get("do_sample", False) and k.get("repetition_penalty", 1) == 1
-                and k.get("min_length", 1) == 1)
+    # generation arguments the fixed-length greedy loop reproduces, with the values at which it does (None = any value: without
+    # sampling and with one beam HF ignores it).  Anything else -- eos_token_id, stopping_criteria, no_repeat_ngram_size,
+    # bad_words_ids, min_new_tokens, max_length, logits_processor, ... -- takes the HF path, so the same classifier never decodes
+    # differently by `decode=`.
+    _GREEDY_NEUTRAL = {"num_beams": 1, "do_sample": False, "repetition_penalty": 1, "min_length": 1, "top_p": None,
+                       "temperature": None, "length_penalty": None, "top_k": None}
 
-    def greedy_tokens(self, embs):
+    def _greedy_defaults(self):
+        for key, val in self.generate_kwargs.items():
+            if key not in self._GREEDY_NEUTRAL:
+                return False
+            want = self._GREEDY_NEUTRAL[key]
+            if want is not None and val != want:
+                return False
+        return True
+
+    def _hf_min_length(self, prompt_len):
+        """The `min_length` HF `generate` really applies to a call with `inputs_embeds` (the reference passes min_length = 1,
+        minigpt_base.py:385).  transformers 4.30.0 -- the reference's pin, docker/tpu-docker:32 -- counts generated tokens only, so EOS
+        is suppressed on the first token; later versions subtract the embedded prompt's length (`GenerationMixin.
+        _prepare_generated_length`: max(min_length - inputs_embeds.shape[1], 0)), which turns min_length = 1 into 0.  The greedy loop
+        follows whatever the INSTALLED generate does, so decode="graph" and decode="hf" are the same decode in either environment."""
+        ml = int(self.generate_kwargs.get("min_length", 1) or 0)
+        if self._min_length_minus_prompt is None:
+            import inspect
+            try:
+                from transformers.generation.utils import GenerationMixin
+                src = inspect.getsource(GenerationMixin._prepare_generated_length)
+                self._min_length_minus_prompt = ("min_length - inputs_tensor.shape[1]" in src) or ("min_length -= inputs_tensor.shape[1]" in src)
+            except Exception:
+                self._min_length_minus_prompt = False
+        return max(ml - int(prompt_len), 0) if self._min_length_minus_prompt else ml
+
+    def greedy_tokens(self, embs, return_logits=False):
         """What `generate(inputs_embeds=embs, attention_mask=ones, max_new_tokens=n, do_sample=False, min_length=1, ...)` returns for
         prompts without padding, as a straight loop of the model's own forward calls: [B, n] token ids, pad_token_id after a row's
         EOS.  (HF additionally stops, and truncates, at the step where every row has finished; the extra columns here are pad ids,
@@ -299,7 +375,7 @@ class MiniGPT4Classifier:
         pos = torch.arange(L, device=embs.device).unsqueeze(0)
         out = llm(inputs_embeds=embs, position_ids=pos, past_key_values=cache, use_cache=True, logits_to_keep=1)
         logits = out.logits[:, -1, :].float()
-        if eos_ids:                                                    # MinLengthLogitsProcessor(min_length = 1): no EOS first
+        if eos_ids and self._hf_min_length(L) > 0:                     # MinLengthLogitsProcessor: no EOS on the first token
             key = (str(embs.device), logits.shape[-1])
             if self._eos_mask is None or self._eos_mask[0] != key:     # built outside any capture (the warm-up run comes first)
                 m = torch.zeros(logits.shape[-1], dtype=torch.bool)
@@ -307,8 +383,10 @@ class MiniGPT4Classifier:
                 self._eos_mask = (key, m.to(embs.device))
             logits = logits.masked_fill(self._eos_mask[1], float("-inf"))
         unfinished = torch.ones(B, dtype=torch.long, device=embs.device)
-        tokens = []
+        tokens, step_logits = [], []
         for i in range(self.max_new_tokens):
+            if return_logits:
+                step_logits.append(logits)
             nxt = logits.argmax(dim=-1)
             nxt = nxt * unfinished + pad * (1 - unfinished)
             tokens.append(nxt)
@@ -319,12 +397,25 @@ class MiniGPT4Classifier:
             pos = torch.full((1, 1), L + i, device=embs.device, dtype=torch.long)
             out = llm(input_ids=nxt[:, None], position_ids=pos, past_key_values=cache, use_cache=True, logits_to_keep=1)
             logits = out.logits[:, -1, :].float()
+        if return_logits:                                              # tests: the per-step logits the argmax was taken on
+            return torch.stack(tokens, dim=1), torch.stack(step_logits, dim=1)
         return torch.stack(tokens, dim=1)
 
     def _generate_graph(self, embs):
-        key = (embs.shape[0], embs.shape[1], embs.dtype)
+        """One captured hipGraph per (batch, prompt length, dtype, device, max_new_tokens, routed prefill), kept in an LRU of
+        `max_graphs` entries: a graph pins its private pool -- the pre-allocated K / V of every layer plus activations, ~6.7 GB of K / V
+        alone at 200 rows x 32 layers x 64 positions -- and ragged last batches or new prompt lengths add entries; the least recently
+        used one is dropped (graph and static tensors freed) before a new capture."""
+        key = (embs.shape[0], embs.shape[1], embs.dtype, embs.device.index, self.max_new_tokens, bool(self.routed_linears))
         entry = self._graphs.get(key)
+        if entry is not None:
+            self._graphs.move_to_end(key)
         if entry is None:
+            while len(self._graphs) >= max(1, int(self.max_graphs)):
+                _, old = self._graphs.popitem(last=False)
+                del old
+                self.decode_stats["graph_evictions"] += 1
+                torch.cuda.empty_cache()                                # return the evicted graph's pool before capturing again
             static_in = embs.clone()
             side = torch.cuda.Stream(device=embs.device)
             side.wait_stream(torch.cuda.current_stream())

@@ -68,6 +68,53 @@ class Smooth(object):
         self.non_certifiable = frozenset(int(c) for c in non_certifiable)
         self._next_sample = 0
         self._lib = _lib.lib()
+        self._timing = None                                # see collect_timing()
+
+    # ------------------------------------------------------------------ per-rank timing (measurement only)
+    def collect_timing(self, on: bool = True):
+        """Start (or stop) recording, for every `_sample_noise`-type call, HIP events around this rank's classifier pass and around
+        the all-reduce, plus the host time spent inside `dist.all_reduce`.  Nothing is synchronised while recording; `timing()`
+        resolves the events.  Used by bench.py so that a multi-GPU line explains itself (compute vs collective per rank)."""
+        self._timing = {"compute": [], "allreduce": [], "allreduce_host_s": 0.0, "calls": 0} if on else None
+
+    def timing(self):
+        """-> dict(compute_ms, allreduce_ms, allreduce_host_ms, calls) of this rank since collect_timing(True) (synchronises)."""
+        t = self._timing
+        if t is None:
+            return None
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        ms = lambda pairs: float(sum(a.elapsed_time(b) for a, b in pairs))
+        return {"compute_ms": ms(t["compute"]), "allreduce_ms": ms(t["allreduce"]), "allreduce_host_ms": 1e3 * t["allreduce_host_s"],
+                "calls": t["calls"]}
+
+    def _timed_compute(self, fn):
+        t = self._timing
+        if t is None or not torch.cuda.is_available():
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        t["compute"].append((e0, e1))
+        t["calls"] += 1
+        return out
+
+    def _all_reduce(self, counts):
+        """The ONE collective of a `_sample_noise` (C1): SUM of the int64 vote histograms over the ranks."""
+        import time
+        import torch.distributed as dist
+        t = self._timing
+        if t is None or not counts.is_cuda:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        h0 = time.perf_counter()
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
+        t["allreduce_host_s"] += time.perf_counter() - h0
+        e1.record()
+        t["allreduce"].append((e0, e1))
 
     # ------------------------------------------------------------------ reference API
     def certify(self, x: torch.tensor, n0: int, n: int, alpha: float, batch_size: int) -> (int, float):
@@ -99,11 +146,10 @@ class Smooth(object):
         lo_a, hi_a = shard_range(n0, rank, world)
         lo_b, hi_b = shard_range(n, rank, world, mirrored=True)
         with torch.no_grad():
-            counts = self.base_classifier.sample_counts_pair(x, first + lo_a, hi_a - lo_a, first + n0 + lo_b, hi_b - lo_b,
-                                                             batch_size, float(self.sigma), self.seed)
+            counts = self._timed_compute(lambda: self.base_classifier.sample_counts_pair(
+                x, first + lo_a, hi_a - lo_a, first + n0 + lo_b, hi_b - lo_b, batch_size, float(self.sigma), self.seed))
         if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
+            self._all_reduce(counts)
         if self.device_stats and counts.is_cuda:
             return counts, None                            # histograms stay on the device (certify finishes there)
         c = counts.cpu().numpy().astype(int)
@@ -126,11 +172,10 @@ class Smooth(object):
         lo_a, hi_a = shard_range(n0, rank, world)
         lo_b, hi_b = shard_range(n, rank, world, mirrored=True)
         with torch.no_grad():
-            counts = bc.sample_counts_images(xs, first + lo_a, hi_a - lo_a, first + n0 + lo_b, hi_b - lo_b, n0 + n,
-                                             float(self.sigma), self.seed)
+            counts = self._timed_compute(lambda: bc.sample_counts_images(xs, first + lo_a, hi_a - lo_a, first + n0 + lo_b, hi_b - lo_b,
+                                                                          n0 + n, float(self.sigma), self.seed))
         if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
+            self._all_reduce(counts)
         c = counts.cpu().numpy().astype(int)
         return [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(G)]
 
@@ -154,10 +199,10 @@ class Smooth(object):
         rank, world = _world(self.process_group)
         lo, hi = shard_range(num, rank, world)
         with torch.no_grad():
-            counts = bc.sample_counts_images(xs, first + lo, hi - lo, 0, 0, stride, float(self.sigma), self.seed)[:, 0].contiguous()
+            counts = self._timed_compute(lambda: bc.sample_counts_images(xs, first + lo, hi - lo, 0, 0, stride, float(self.sigma),
+                                                                          self.seed))[:, 0].contiguous()
         if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)
+            self._all_reduce(counts)
         return counts.cpu().numpy().astype(int)
 
     def predict(self, x: torch.tensor, n: int, alpha: float, batch_size: int) -> int:
@@ -184,10 +229,9 @@ class Smooth(object):
         rank, world = _world(self.process_group)
         lo, hi = shard_range(num, rank, world)
         with torch.no_grad():
-            counts = self._local_counts(x, first + lo, hi - lo, batch_size)
+            counts = self._timed_compute(lambda: self._local_counts(x, first + lo, hi - lo, batch_size))
         if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.process_group)   # the one collective (C1)
+            self._all_reduce(counts)                       # the one collective (C1)
         return counts
 
     def _sample_noise(self, x: torch.tensor, num: int, batch_size) -> np.ndarray:

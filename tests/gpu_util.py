@@ -33,3 +33,4 @@ def rel_err(got, ref):
     got = torch.as_tensor(got).float().cpu()
     ref = torch.as_tensor(ref).float().cpu()
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+

@@ -127,6 +127,13 @@ def test_bench_self_launches_its_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["collective_backend"] == "gloo" and line["rccl_ranks"] == 0
     assert line["value"] > 0 and line["single_image_certify_ms"] > 0
+    # a multi-rank line explains itself: per-rank classifier / all-reduce / total times and the number of ranks the collective summed over
+    rk = line["ranks"]
+    assert rk["summed_ranks"] == 2 and len(rk["per_rank_ms"]) == 2
+    for r in rk["per_rank_ms"]:
+        assert r["classifier_passes"] > 0 and r["all_reduce_device"] >= 0 and r["sample_noise_calls"] >= 1
+        assert r["total"] >= r["classifier_passes"] * 0.5
+    assert rk["rank_total_ms_max"] >= rk["rank_total_ms_min"] > 0
     if torch.cuda.device_count() < 8:
         env.pop("CGPT_BENCH_ONE_GPU_REHEARSAL")
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],

@@ -275,6 +275,75 @@ def test_configs2_full_minigpt4_certify_n100_sigma05(encode_img_pair):
     torch.cuda.empty_cache()
 
 
+def test_configs2_graph_decode_and_cgpt_prefill_follow_hf_generate_at_vicuna_width(encode_img_pair):
+    """The configs[2] FAST path (what `bench.py --workload minigpt4` measures: decode="graph", prefill_linear="cgpt") against the
+    reference's call, `llama_model.generate` with its fixed arguments (minigpt_base.py:418-431; decode="hf"), at Vicuna-7B's widths on
+    the same 200 noisy rows of a full-size `encode_img`, 20 new tokens, token by token:
+      * the straight greedy loop (the model's own forward, pre-allocated K / V) run eagerly gives HF's tokens for EVERY row and HF's
+        logits bit for bit -- the loop itself is the same decode;
+      * with the prefill's linears through this library's GEMM the first-token logits agree within fp16 rounding noise (<= 4 ulp of
+        the largest logit: fp16 operands and results, fp32 accumulation in another order);
+      * captured into a hipGraph (other vendor kernels get picked under capture) and / or with the routed prefill, a row may leave HF's
+        trajectory ONLY at a step where HF's own top-2 margin is within that noise (eps = 2 x the measured logit difference, at least 2
+        ulp); every decisive row gives the identical answer, so flips <= non-decisive rows.
+    A random-init decoder has near-uniform logits (margins of 0 - 2 ulp are common), which is why not every row can be identical."""
+    import contextlib
+    from certifiedgpt_amd.minigpt4 import MiniGPT4Classifier, WordHashTokenizer, prepare_texts, _LinearRoute
+    from certifiedgpt_amd.agents.label_adapter import AnswerLabelMap
+    from certifiedgpt_amd.minigpt4 import greedy_decode_parity, fp16_ulp
+    enc, cfg, _ = encode_img_pair
+    llm = _vicuna_width_decoder()
+    tok = WordHashTokenizer(32000)
+    prompt = prepare_texts(["<Img><ImageHere></Img> [vqa] what is shown in the picture"])[0]
+    x = torch.from_numpy(mo.synthetic_image(cfg, seed=11)).to(DEV)
+    B, n, sigma, seed = 200, 20, 0.5, 42
+    emb = torch.cat([enc.encode_img_noisy(x, lo, min(enc.max_batch, B - lo), sigma, seed) for lo in range(0, B, enc.max_batch)]).to(torch.float16)
+    assert emb.shape == (B, 32, 4096)
+    lm = AnswerLabelMap(4, ())
+    hf = MiniGPT4Classifier(enc, llm, tok, prompt, lm, max_new_tokens=n, max_batch=B, decode="hf")
+    segs = hf._segment_embeddings(prompt, emb.device)
+    embs = torch.cat([segs[0].expand(B, -1, -1), emb, segs[1].expand(B, -1, -1)], dim=1)
+    with torch.no_grad():
+        out = llm.generate(inputs_embeds=embs, attention_mask=torch.ones(embs.shape[:2], dtype=torch.int, device=DEV), max_new_tokens=n,
+                           output_scores=True, return_dict_in_generate=True, **hf.generate_kwargs)
+    hf_tokens, hf_scores = out.sequences, torch.stack(out.scores, dim=1).float()
+    ulp = fp16_ulp(float(hf_scores[torch.isfinite(hf_scores)].abs().max()))
+    gr = MiniGPT4Classifier(enc, llm, tok, prompt, lm, max_new_tokens=n, max_batch=B, decode="graph")
+    gc = MiniGPT4Classifier(enc, llm, tok, prompt, lm, max_new_tokens=n, max_batch=B, decode="graph", prefill_linear="cgpt")
+    assert gc.routed_linears > 0
+    with torch.no_grad():
+        t_eager, l_eager = gr.greedy_tokens(embs, return_logits=True)
+        with _LinearRoute.enabled():
+            t_routed, l_routed = gc.greedy_tokens(embs, return_logits=True)
+    S = hf_tokens.shape[1]
+    assert torch.equal(t_eager[:, :S], hf_tokens), "the eager greedy loop is not HF's decode"
+    fin = torch.isfinite(hf_scores[:, 0]) & torch.isfinite(l_eager[:, 0])
+    assert torch.equal(torch.isfinite(hf_scores[:, 0]), torch.isfinite(l_eager[:, 0]))     # the same EOS suppression as the installed generate
+    assert torch.equal(l_eager[:, 0][fin], hf_scores[:, 0][fin])          # first-token logits: bit-identical to HF's processed scores
+    assert torch.equal(l_eager[:, 1:S], hf_scores[:, 1:S])                # and every later step's
+    d_first = float((l_routed[:, 0][fin] - hf_scores[:, 0][fin]).abs().max())
+    assert d_first <= 4 * ulp, (d_first, ulp)                              # routed prefill: fp16 noise
+    eps = max(2.0 * d_first, 2.0 * ulp)
+    report = {"routed eager": greedy_decode_parity(hf_tokens, hf_scores, t_routed, eps)}
+    with torch.no_grad():
+        report["graph"] = greedy_decode_parity(hf_tokens, hf_scores, gr._generate_graph(embs), eps)
+        report["graph + cgpt prefill"] = greedy_decode_parity(hf_tokens, hf_scores, gc._generate_graph(embs), eps)
+    # and the answers the classifier hands to the label adapter
+    ans_hf = hf.generate_from_embeds(emb, prompt)
+    ans_gc = gc.generate_from_embeds(emb, prompt)
+    print(f"[configs2 fast path] fp16 ulp at the largest logit {ulp:.4g}, first-token |dlogit| routed-vs-HF {d_first:.4g}, eps {eps:.4g}; "
+          + "; ".join(f"{k}: {v['identical']}/{B} rows identical, {v['decisive_identical']}/{v['decisive']} decisive rows identical, largest HF margin "
+                      f"at a first divergence {v['max_margin_at_divergence']:.4g}" for k, v in report.items())
+          + f"; answers equal (graph + cgpt vs hf) {sum(int(a == b) for a, b in zip(ans_hf, ans_gc))}/{B}", flush=True)
+    for name, v in report.items():
+        assert not v["violations"], (name, v)
+        assert v["decisive_identical"] == v["decisive"] and v["diverged"] <= B - v["decisive"], (name, v)
+        assert v["decisive"] >= B // 10, (name, v)                         # the rule must bite on a meaningful number of rows
+    assert gr.decode_stats["hf_calls"] == 0 and gc.decode_stats["graph_replays"] >= 2
+    del llm
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------ ViT-G at the reference's own image size (448 x 448, T = 1025)
 def test_vitg_448_streaming_attention_matches_cpu_oracle():
     """SURVEY 8(f) rank 3 at full size: ViT-G + head on one noisy 448 x 448 sample (T = 1025 tokens, minigpt4.py:32 -- K / V no longer

@@ -192,6 +192,49 @@ def test_vitg_counts_invariant_to_batching_and_sharding(vitg):
     assert torch.equal(torch.bincount(logits.argmax(1), minlength=1000), full)
 
 
+def test_vitg_n1000_sharded_125_per_gpu_equals_one_pass_and_oracle_statistics():
+    """BASELINE configs[3] at its real size (ViT-G + head, 224x224, sigma = 0.5): `_sample_noise(N = 1000)` as the eight
+    125-sample shards an 8-GPU job runs (one 125-sample classifier batch per rank) gives the histogram of one pass bit for bit; and
+    `Smooth.predict` (smoothing.py:58-79) / `Smooth.certify` (:29-56) at N = 1000 take the decisions of the CPU statistics oracle on
+    those counts, on the host path and with the statistics finished on the device.  About 4 000 forwards, ~2.5 s of GPU."""
+    cfg = mo.Config(mode=mo.MODE_VIT_HEAD, num_classes=1000)
+    clf = make_classifier(cfg, max_batch=125)
+    try:
+        clf.init_synthetic(seed=0)
+        x = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+        sigma, seed = 0.5, 42
+        full = clf.sample_counts(x, 0, 1000, 125, sigma, seed)
+        assert int(full.sum()) == 1000
+        parts = torch.zeros_like(full)
+        for r in range(8):
+            lo, hi = cg.shard_range(1000, r, 8)
+            assert hi - lo == 125
+            clf.sample_counts(x, lo, hi - lo, 125, sigma, seed, counts=parts)
+        assert torch.equal(full, parts)
+        ragged = clf.sample_counts(x, 0, 1000, 99, sigma, seed)                 # 10 batches of 99 + one of 10
+        assert torch.equal(full, ragged)
+        est = clf.sample_counts(x, 1000, 1000, 125, sigma, seed)               # certify's estimation range
+        # the mirrored 8-way partition of the estimation range (Smooth._sample_noise_pair) is a partition too
+        parts_b = torch.zeros_like(est)
+        for r in range(8):
+            lo, hi = cg.shard_range(1000, r, 8, mirrored=True)
+            clf.sample_counts(x, 1000 + lo, hi - lo, 125, sigma, seed, counts=parts_b)
+        assert torch.equal(est, parts_b)
+        c_sel, c_est = full.cpu().numpy(), est.cpu().numpy()
+        for alpha in (0.001, 0.05):
+            for dev_stats in (False, True):
+                s = cg.Smooth(clf, 1000, sigma, seed=seed, device_stats=dev_stats)
+                got = s.predict(x, 1000, alpha, 125)
+                want = so.predict_from_counts(c_sel, alpha)
+                assert got == want and ((got == cg.Smooth.ABSTAIN and type(got) is int) or isinstance(got, np.int64)), (alpha, dev_stats)
+                s.reset()
+                lab, rad = s.certify(x, 1000, 1000, alpha, 125)
+                olab, orad = so.certify_from_counts(c_sel, c_est, 1000, alpha, sigma)
+                assert lab == olab and abs(rad - orad) <= 1e-9, (alpha, dev_stats, (lab, rad), (olab, orad))
+    finally:
+        clf.close()
+
+
 def test_vitg_matches_oracle_on_two_samples(vitg):
     """Full-size numerical check: 2 noisy samples through ViT-G on the GPU vs the fp32 CPU oracle with the device's weights."""
     clf, cfg = vitg
