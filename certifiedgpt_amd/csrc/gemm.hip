@@ -759,7 +759,6 @@ hipError_t launch_v3_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
 }  // namespace
 
 int g_gemm_kernel = 0;
-int g_gemm_plan = 1;       // gemm9 column plans: 0 never, 1 when the cost model predicts a gain, 2 best plan always, 11..13 forced widths (tests)
 int g_gemm_ablate = 0;
 int g_gemm_group_m = 4;   // measured: 4 ~ 8 > 2 > 16 (profiles/r01/gemm_variants.txt)
 unsigned long long* g_gemm_dbg = nullptr;

@@ -37,10 +37,6 @@
 //    eight 64-bit pointers, 247 -> 220 VGPRs): bit-identical, but the K loop is ~2 % slower (fc2 864 vs 846 us raw; 9.81 vs 10.00 img/s
 //    in the model on one box).
 #include "gemm_common.h"
-#include <map>
-#include <mutex>
-#include <tuple>
-#include <vector>
 
 namespace cgpt {
 
@@ -65,64 +61,36 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     half_t* const scratch_all = smem9 + 2 * STAGE;
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // lane id, recomputed where it is needed (two VALU instructions) instead of kept in a register across the K loops: the kernel sits at
-    // the 256-register limit, and a spilled lane id is reloaded from scratch by a VECTOR load whose wait drains the LDS-DMA queue
-    auto lane_id = [&]() __attribute__((always_inline)) -> int {
-        int l;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-        return l;
-    };
-    const int lane = lane_id();
     const int wr = wave >> 2, wc = wave & 3;
     const bool late = wave >= 4;                                           // the half that runs one slot behind
     const int r15 = lane & 15, g = lane >> 4;
 
     const int tiles_m = (p.M + BM2 - 1) / BM2;
     const int tiles_n = (p.N + BN_ - 1) / BN_;
-    const bool plan = p.plan_n > 0;                                        // column plan: tiles of 64 .. 256 columns, widest first
-    const int ntiles = tiles_m * (plan ? p.plan_n : tiles_n);
+    const int ntiles = tiles_m * tiles_n;
     const int nk = p.K / BK;
     const bool split_n = (p.N % 256) == 128 && p.N >= 384 && !(p.ablate & 16384);
-    // virtual tile v -> tile row, first column, width in units of 64 columns (= column tiles of 16 per wave)
-    auto locate = [&](int v, int& tm, int& ncol0, int& w) {
-        if (plan) {                                                        // every tile row of a column tile, column tiles widest first
-            const int tn = v / tiles_m;
-            tm = v - tn * tiles_m;
-            const int e = p.plan[__builtin_amdgcn_readfirstlane(tn)];
-            ncol0 = 64 * (e >> 8);
-            w = e & 255;
-        } else {
-            int tn;
-            tile_of_virtual_block(v, ntiles, tiles_m, tiles_n, tm, tn, p.group_m);
-            const bool narrow = split_n && tn >= tiles_n - 2;
-            ncol0 = narrow ? (tiles_n - 2) * BN_ + (tn - (tiles_n - 2)) * 192 : tn * BN_;
-            w = narrow ? 3 : 4;
-        }
-    };
-    // k-th tile of this workgroup.  Plan mode walks the width-sorted list in a serpentine (round k forwards, k + 1 backwards), so the
-    // workgroup that took the widest tile of one round takes the narrowest of the next (LPT-like balance, evaluated by the host planner).
-    auto tile_of_round = [&](int k) -> int {
-        const int G = (int)gridDim.x, b = (int)blockIdx.x;
-        return k * G + ((plan && (k & 1)) ? G - 1 - b : b);
-    };
 
     // ------------------------------------------------------------------ request side (runs ~1.5 K-tiles ahead of the MFMAs)
     // piece i (0, 1) of this wave covers part rows 16*(wave&3 | wave&1) + 8*i + (lane>>3); source 16-byte chunk swizzled per row.
     // A(m1) is A(m0) + 64 rows and (wide tiles) B(n1) is B(n0) + 32 rows: the swizzle (row >> 1) & 7 is the same, so they differ by a
     // wave-uniform offset.  All offsets are bytes.
+    const int lr = lane >> 3, cpos = lane & 7;
     const half_t* src_a0[2];   // A(m0): tile rows (wave>>2)*128 +  0 + 16*(wave&3) + 8*i + lr
     const half_t* src_a1[2];   // A(m1):                        + 64
     const half_t* src_b0[2];   // B(n0): W rows (wave>>1)*64 + 16*(wave&1) + 8*i + lr          (narrow: (wave>>1)*48 + ...)
     const half_t* src_b1[2];   // B(n1):                    + 32                               (narrow: one piece, (wave>>1)*48 + 32 + 8*(wave&1) + lr)
     int dst_a0, dst_a1, dst_b0[2], dst_b1[2];                               // LDS offsets (halfs) inside a stage, piece 0 (A: piece 1 = + 8 rows)
-    int rt = blockIdx.x, rround = 0, rkt = 0, rc = 0;                       // request cursor: tile (and its round), K-tile in it, stream K-tile counter
+    int rt = blockIdx.x, rkt = 0, rc = 0;                                   // request cursor: tile, K-tile in it, stream K-tile counter
     bool req_ok = rt < ntiles;
     auto set_req_tile = [&](int t) {
-        int tm, ncol0, w;
-        locate(t, tm, ncol0, w);
+        int tm, tn;
+        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn, p.group_m);
+        const bool narrow = split_n && tn >= tiles_n - 2;
+        const int ncol0 = narrow ? (tiles_n - 2) * BN_ + (tn - (tiles_n - 2)) * 192 : tn * BN_;
         const int ra = (wave >> 2) * 128 + 16 * (wave & 3);
-        const int ln = lane_id(), lr = ln >> 3, cpos = ln & 7;
         dst_a0 = ra * BK;
         dst_a1 = (ra + 64) * BK;
 #pragma unroll
@@ -130,13 +98,9 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             const int r0 = ra + 8 * i + lr, r1 = r0 + 64;
             src_a0[i] = p.A + (int64_t)(tm * BM2 + r0) * p.lda + ((cpos ^ ((r0 >> 1) & 7)) << 3);
             src_a1[i] = p.A + (int64_t)(tm * BM2 + r1) * p.lda + ((cpos ^ ((r1 >> 1) & 7)) << 3);
-            // W rows of the two B parts (LDS row == row inside the tile's W image, 16 w rows per wave column).  B(n0) = the first
-            // min(32, 16 w) rows of every wave column, B(n1) = the rest; a part with fewer than 32 rows per wave column is requested
-            // with duplicate pieces (w = 3: both pieces of B(n1) are the same 8 rows; w <= 2: B(n1) repeats B(n0)) -- idempotent, and
-            // the counted waits see the same eight requests per K-tile for every width.
-            const int q16 = (wave >> 1) * 16 * w, h = wave & 1;
-            const int b0 = q16 + (w >= 2 ? 16 * h + 8 * i : 8 * i);
-            const int b1 = w == 4 ? b0 + 32 : (w == 3 ? q16 + 32 + 8 * h : b0);
+            // W rows of the two B parts (LDS row == row inside the tile's W image)
+            const int b0 = narrow ? (wave >> 1) * 48 + 16 * (wave & 1) + 8 * i : (wave >> 1) * 64 + 16 * (wave & 1) + 8 * i;
+            const int b1 = narrow ? (wave >> 1) * 48 + 32 + 8 * (wave & 1) : b0 + 32;   // narrow: both pieces are the same 8 rows (idempotent)
             dst_b0[i] = A_ELEMS + b0 * BK;
             dst_b1[i] = A_ELEMS + b1 * BK;
             src_b0[i] = p.W + (int64_t)(ncol0 + b0 + lr) * p.ldw + ((cpos ^ (((b0 + lr) >> 1) & 7)) << 3);
@@ -165,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             ++rc;                                                           // K-tile complete: advance the cursor
             if (++rkt == nk) {
                 rkt = 0;
-                rt = tile_of_round(++rround);
+                rt += gridDim.x;
                 req_ok = rt < ntiles;
                 if (req_ok) set_req_tile(rt);
             }
@@ -176,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     const int sw = (r15 >> 1) & 7;
     const int k_off0 = ((g ^ sw) << 3), k_off1 = (((4 + g) ^ sw) << 3);
     const int a_rd = (wr * 128 + r15) * BK;
+    const int b_rd_wide = A_ELEMS + (wc * 64 + r15) * BK, b_rd_narrow = A_ELEMS + (wc * 48 + r15) * BK;
 
     f32x4 acc[8][4];
     f16x8 af[4][2], bf0[2][2], bf1[2][2];
@@ -183,6 +148,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #define CGPT_SLOT_END CGPT_FENCE __builtin_amdgcn_s_barrier(); CGPT_FENCE
 
     int c = 0;                                                              // stream K-tile counter of the compute side
+    int t = blockIdx.x;
     if (req_ok) {
         set_req_tile(rt);
         // prime the stream: all of K-tile 0 and the first three parts of K-tile 1 (L(P0) of K-tile 0 then requests A(m1) of 1)
@@ -210,13 +176,13 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #define CGPT9_PH(k)
 #endif
     auto tile_body = [&](auto tnv_tag, int tm, int ncol0) __attribute__((always_inline)) {
-        constexpr int TNv = decltype(tnv_tag)::value;                       // column tiles of 16 per wave: 4 (256-column tile) .. 1 (64)
-        constexpr int N0 = TNv < 2 ? TNv : 2;                               // column tiles of the n0 half
-        constexpr int N1 = TNv > 2 ? TNv - 2 : 0;                           // column tiles of the n1 half
-        constexpr int wcols = 16 * TNv;
-        const int b_rd = A_ELEMS + (wc * wcols + (lane_id() & 15)) * BK;
+        constexpr int TNv = decltype(tnv_tag)::value;                       // column tiles of 16 per wave: 4, or 3 (192-column tile)
+        constexpr bool NARROW = TNv == 3;
+        constexpr int N1 = TNv - 2;                                         // column tiles of the n1 half
+        const int b_rd = NARROW ? b_rd_narrow : b_rd_wide;
+        const int wcols = NARROW ? 48 : 64;
         if (p.bias) {                                                       // 64 bias values of this wave -> its scratch
-            const int bc = min(ncol0 + wc * wcols + lane_id(), p.N - 1);
+            const int bc = min(ncol0 + wc * wcols + lane, p.N - 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + bc),
                                              (__attribute__((address_space(3))) void*)bias_lds, 4, 0, 0);
         }
@@ -240,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             // ---------------- P0 = (m0; n0, n1)
             if constexpr (RD) {
 #pragma unroll
-            for (int j = 0; j < N0; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 bf0[j][0] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + k_off0);
                 bf0[j][1] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 16 * BK + k_off1);
             }
@@ -267,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < N0; ++j)
+                    for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -308,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < N0; ++j)
+                    for (int j = 0; j < 2; ++j)
                         acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[4 + i][j], 0, 0, 0);
             CGPT9_PH(6)
             CGPT_SLOT_END
@@ -339,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         for (int j = 0; j < TNv; ++j)
             bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(bias_lds + j * 16 + 4 * eg) : f32x4{0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // before the first pass overwrites the scratch
-        const bool full = (tm + 1) * BM2 <= p.M && ncol0 + 64 * TNv <= p.N;
+        const bool full = (tm + 1) * BM2 <= p.M && ncol0 + (NARROW ? 192 : BN_) <= p.N;
         constexpr bool F16_OUT = EPI == EPI_F16 || EPI == EPI_F16_GELU;
         if (F16_OUT && full && (p.ldo & 7) == 0 && !(p.ablate & 512)) {
             // fp16 output of a full tile, transposed through the wave's 4-KiB scratch: four passes of 32 rows x 64 columns; rows are
@@ -376,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int row = it * 8 + row_rd;
-                        if (TNv == 4 || ch_rd < 2 * TNv) {
+                        if (!NARROW || ch_rd < 6) {
                             const f16x8 o = *reinterpret_cast<const f16x8*>(scr + row * 64 + ((ch_rd ^ (row & 7)) * 8));
                             CGPT9_STORE16(o, reinterpret_cast<f16x8*>(dst0 + it * step));
                         }
@@ -385,13 +351,13 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
                 }
             }
         } else {
-            if constexpr (TNv < 4) {
-                f32x4 accn[8][TNv];
+            if constexpr (NARROW) {
+                f32x4 accn[8][3];
 #pragma unroll
                 for (int i2 = 0; i2 < 8; ++i2)
 #pragma unroll
-                    for (int j2 = 0; j2 < TNv; ++j2) accn[i2][j2] = acc[i2][j2];
-                gemm_epilogue_256<EPI, 8, TNv>(p, accn, bias4, tm * BM2 + wr * 128 + e15, ncol0 + wc * wcols + 4 * eg, full);
+                    for (int j2 = 0; j2 < 3; ++j2) accn[i2][j2] = acc[i2][j2];
+                gemm_epilogue_256<EPI, 8, 3>(p, accn, bias4, tm * BM2 + wr * 128 + e15, ncol0 + wc * 48 + 4 * eg, full);
             } else {
                 gemm_epilogue_256<EPI, 8, 4>(p, acc, bias4, tm * BM2 + wr * 128 + e15, ncol0 + wc * 64 + 4 * eg, full);
             }
@@ -401,18 +367,16 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #endif
     };
 
-    for (int round = 0;; ++round) {
-        const int t = tile_of_round(round);
-        if (t >= ntiles) break;
-        int tm, ncol0, w;
-        locate(t, tm, ncol0, w);
-        if (w == 4) tile_body(IntTag9<4>{}, tm, ncol0);
-        else if (w == 3) tile_body(IntTag9<3>{}, tm, ncol0);
-        else if (w == 2) tile_body(IntTag9<2>{}, tm, ncol0);
-        else tile_body(IntTag9<1>{}, tm, ncol0);
+    for (; t < ntiles; t += gridDim.x) {
+        int tm, tn;
+        tile_of_virtual_block(t, ntiles, tiles_m, tiles_n, tm, tn, p.group_m);
+        const bool narrow = split_n && tn >= tiles_n - 2;
+        const int ncol0 = narrow ? (tiles_n - 2) * BN_ + (tn - (tiles_n - 2)) * 192 : tn * BN_;
+        if (narrow) tile_body(IntTag9<3>{}, tm, ncol0);
+        else tile_body(IntTag9<4>{}, tm, ncol0);
     }
 #ifdef CGPT_STAMPS
-    if (p.dbg && lane_id() == 0) {
+    if (p.dbg && lane == 0) {
         unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
         d[0] = __builtin_amdgcn_s_memtime() - st_begin; d[1] = st_first; d[2] = st_loop; d[3] = st_epi;
         unsigned long long* e = p.dbg + (size_t)gridDim.x * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8;   // second table: phase stamps
@@ -423,111 +387,8 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #undef CGPT_SLOT_END
 }
 
-// ---------------------------------------------------------------------------------------------------- column plans (host)
-// With few tile rows (a rank's 25-sample shard of one image is 26 tile rows) the classic tiling -- 256-column tiles, two 192-column
-// ones for N = 256 k + 128 -- leaves workgroups idle or gives some of them a whole extra tile: 156 tiles on 256 CUs for proj / fc2,
-// 624 = 2.44 x 256 for fc1.  A column plan cuts N into tiles of 64 .. 256 columns so that the kernel's walk (width-sorted tiles,
-// serpentine rounds) loads the workgroups evenly; every output element keeps its K order, so results are bit-identical.  The cost
-// of a tile by its width is measured (tools/gemm_plan_bench.py): narrow tiles are L-segment-bound, a 192-column tile costs 0.87
-// of a 256-column one, narrower ones hardly less.
-constexpr float kTileCost[5] = {0.f, 0.78f, 0.82f, 0.87f, 1.0f};
-
-struct ColPlan {
-    int n = 0;
-    unsigned short start[kGemmPlanMax];
-    unsigned char w[kGemmPlanMax];
-    float makespan = 0.f, classic = 0.f;
-};
-
-// makespan of the kernel's walk over a plan: virtual tile v = (column tile v / R, tile row v % R), workgroup of round k = v / G
-float plan_makespan(const unsigned char* w, int ncol, int R, int G) {
-    const int ntiles = ncol * R, grid = ntiles < G ? ntiles : G;
-    std::vector<float> load(grid, 0.f);
-    for (int v = 0; v < ntiles; ++v) {
-        const int k = v / grid, pos = v - k * grid;
-        load[(k & 1) ? grid - 1 - pos : pos] += kTileCost[w[v / R]];
-    }
-    float m = 0.f;
-    for (float x : load) m = x > m ? x : m;
-    return m;
-}
-
-float classic_makespan(int R, int N, int G, int group_m) {
-    const int tiles_n = (N + 255) / 256, ntiles = R * tiles_n, grid = ntiles < G ? ntiles : G;
-    const bool split_n = (N % 256) == 128 && N >= 384;
-    std::vector<float> load(grid, 0.f);
-    for (int v = 0; v < ntiles; ++v) {
-        int tm, tn;
-        tile_of_virtual_block(v, ntiles, R, tiles_n, tm, tn, group_m);
-        load[v % grid] += kTileCost[(split_n && tn >= tiles_n - 2) ? 3 : 4];
-    }
-    float m = 0.f;
-    for (float x : load) m = x > m ? x : m;
-    return m;
-}
-
-void fill_plan(ColPlan& pl, int a4, int a3, int a2, int a1) {
-    pl.n = 0;
-    int col = 0;
-    const int cnt[5] = {0, a1, a2, a3, a4};
-    for (int w = 4; w >= 1; --w)
-        for (int i = 0; i < cnt[w]; ++i) {
-            pl.start[pl.n] = (unsigned short)col;
-            pl.w[pl.n++] = (unsigned char)w;
-            col += w;
-        }
-}
-
-// Best plan for R tile rows x N columns on G workgroups; mode 1: only when the model predicts >= 3 % over the classic tiling, 2: the best
-// plan whatever it gains, 11 / 12 / 13: every column tile 64 / 128 / 192 wide plus what is left (tests of the narrow tile bodies).
-bool choose_plan(int R, int N, int G, int group_m, int mode, ColPlan& out) {
-    const int U = (N + 63) / 64;
-    if (mode <= 0 || U < 1) return false;
-    if (mode >= 11 && mode <= 13) {
-        const int w = mode - 10, a = U / w, r = U - a * w;
-        int cnt[5] = {0, 0, 0, 0, 0};
-        cnt[w] = a;
-        if (r) cnt[r] += 1;
-        if (cnt[1] + cnt[2] + cnt[3] + cnt[4] > kGemmPlanMax) return false;
-        fill_plan(out, cnt[4], cnt[3], cnt[2], cnt[1]);
-        return true;
-    }
-    const int tiles_n = (N + 255) / 256;
-    if ((long long)R * tiles_n > 12LL * G) return false;                   // many tiles per workgroup: quantisation is below the model's error
-    static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int>, ColPlan> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    auto key = std::make_tuple(R, N, G, group_m);
-    auto it = cache.find(key);
-    if (it == cache.end()) {
-        ColPlan best;
-        best.classic = classic_makespan(R, N, G, group_m);
-        best.makespan = 1e30f;
-        ColPlan cand;
-        for (int a4 = 0; a4 * 4 <= U; ++a4)
-            for (int a3 = 0; a4 * 4 + a3 * 3 <= U; ++a3) {
-                const int r = U - a4 * 4 - a3 * 3, a2 = r / 2, a1 = r & 1;
-                if (a4 + a3 + a2 + a1 > kGemmPlanMax) continue;
-                if (a2 > 2) continue;                                      // 128-column tiles cost almost as much as 192-column ones: leftovers only
-                fill_plan(cand, a4, a3, a2, a1);
-                cand.makespan = plan_makespan(cand.w, cand.n, R, G);
-                if (cand.makespan < best.makespan - 1e-6f || (cand.makespan < best.makespan + 1e-6f && cand.n < best.n)) {
-                    const float cl = best.classic;
-                    best = cand;
-                    best.classic = cl;
-                }
-            }
-        it = cache.emplace(key, best).first;
-    }
-    const ColPlan& b = it->second;
-    if (b.n == 0 || b.makespan > 1e29f) return false;
-    if (mode == 1 && !(b.makespan < 0.97f * b.classic)) return false;
-    out = b;
-    return true;
-}
-
 template <int EPI>
-hipError_t launch_v9(const GemmParams& p_in, hipStream_t stream) {
+hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
     constexpr int lds_bytes = 2 * (256 + 256) * BK * (int)sizeof(half_t) + 32768;   // two stages + epilogue scratch = 160 KiB
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
@@ -542,16 +403,7 @@ hipError_t launch_v9(const GemmParams& p_in, hipStream_t stream) {
         cus[dev] = n > 0 ? n : 256;
         configured[dev] = true;
     }
-    GemmParams p = p_in;
-    const int R = (p.M + 255) / 256;
-    int tiles = R * ((p.N + 255) / 256);
-    ColPlan pl;
-    p.plan_n = 0;
-    if (!(p.ablate & 16384) && choose_plan(R, p.N, cus[dev], p.group_m, g_gemm_plan, pl)) {
-        p.plan_n = pl.n;
-        for (int i = 0; i < pl.n; ++i) p.plan[i] = ((int)pl.start[i] << 8) | (int)pl.w[i];
-        tiles = R * pl.n;
-    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = tiles < cus[dev] ? tiles : cus[dev];                   // one 512-thread workgroup per CU (LDS-limited), persistent
     hipLaunchKernelGGL((gemm9_f16_kernel<EPI>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();

@@ -102,13 +102,13 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int& tm,
 
 // Same map for a VIRTUAL block id t in [0, nwg) (persistent kernel: physical block b walks t = b, b + grid, ...; with a grid
 // that is a multiple of 8, t and b sit on the same XCD).
-__host__ __device__ __forceinline__ void tile_of_virtual_block(int vb, int nwg, int tiles_m, int tiles_n, int& tm, int& tn, int group_m = GROUP_M) {
+__device__ __forceinline__ void tile_of_virtual_block(int vb, int nwg, int tiles_m, int tiles_n, int& tm, int& tn, int group_m = GROUP_M) {
     const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int per_group = group_m * tiles_n;
     const int grp = t / per_group;
     const int first_m = grp * group_m;
-    const int gsz = (tiles_m - first_m) < group_m ? (tiles_m - first_m) : group_m;
+    const int gsz = min(tiles_m - first_m, group_m);
     const int in_grp = t - grp * per_group;
     tm = first_m + in_grp % gsz;
     tn = in_grp / gsz;

@@ -18,7 +18,6 @@ enum GemmEpilogue {
     EPI_RESID = 3,      // out_f32[m,n] = aux_f32[m,n] + acc + bias[n]  (aux may alias out: x = x + f(x), eva_vit.py:180-181)
     EPI_PATCH = 4       // patch-embed: row m=(b,p) -> out_f32[b*(P+1)+1+p, n] = acc + bias[n] + aux[(1+p), n]  (eva_vit.py:209,337-340)
 };
-constexpr int kGemmPlanMax = 48;
 struct GemmParams {
     const half_t* A; int64_t lda;
     const half_t* W; int64_t ldw;
@@ -30,11 +29,6 @@ struct GemmParams {
     unsigned long long* dbg = nullptr;   // diagnostic builds only (-DCGPT_STAMPS): per-wave cycle sums
     int group_m = 8;              // tile-rows per group in the block->tile map (speed only)
     int ablate = 0;               // lab builds: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs; tests: see launch_gemm
-    // Column plan of the 256-row two-phase kernel (gemm9.hip; filled by its launcher, speed only): plan_n > 0 cuts the N columns into
-    // plan_n column tiles, widest first; plan[i] = (first column / 64) << 8 | width in units of 64 columns (1..4).  32-bit words, so
-    // that the kernel reads them with SCALAR loads (a sub-dword array would be read with vector loads, which count in vmcnt).
-    int plan_n = 0;
-    int plan[kGemmPlanMax] = {};
 };
 hipError_t launch_gemm(int epilogue, const GemmParams& p, hipStream_t stream);
 // gemm9.hip: 256x256 tile, two 32-MFMA phases per K-tile, operand parts requested 1.5 K-tiles ahead by LDS-DMA
@@ -46,7 +40,6 @@ hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);
 extern int g_gemm_ablate;
 extern int g_gemm_group_m;
 extern unsigned long long* g_gemm_dbg;
-extern int g_gemm_plan;     // column plans of the two-phase kernel: 0 = never, 1 = when the model predicts a gain (default), 2 = whenever one exists (tests)
 extern int g_gemm_kernel;   // kernel override (speed only): 0 auto, 1 = 128x128, 3 = 256x128, 4 = 256x256 phased, 14 = 256x256 two-phase quadrant; lab builds: 2, 5..11, 15
 
 // ---------------------------------------------------------------------------------------- attention

@@ -782,12 +782,6 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
         g_gemm_kernel = value;
         return CGPT_OK;
     }
-    if (k == "gemm_plan") {
-        if (!(value == 0 || value == 1 || value == 2 || (value >= 11 && value <= 13)))
-            return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_plan must be 0 (never), 1 (automatic), 2 (best plan always) or 11..13 (forced widths, tests)");
-        g_gemm_plan = value;
-        return CGPT_OK;
-    }
     if (k == "gemm_ablate") {
 #ifndef CGPT_LAB
         if (value & ~(512 | 16384))

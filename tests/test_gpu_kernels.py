@@ -420,46 +420,3 @@ def test_gelu_epilogue_gives_the_same_bits_on_every_kernel_under_load(M, N, K):
     err = (ref[rows].float() - want).abs()
     tol = 1e-3 * want.abs() + 2e-4            # fp16 rounding (2^-11 relative) + accumulation-order noise of the fp32 linear
     assert bool((err <= tol).all()), float((err / tol).max())
-
-
-@pytest.mark.parametrize("M,N,K,epi", [(6425, 1408, 6144, 0), (6425, 6144, 1408, 1), (6425, 4224, 1408, 0), (6425, 1408, 1408, 3),
-                                       (12850, 1408, 192, 0), (3341, 1000, 128, 2), (6425, 768, 64, 0), (2313, 4224, 128, 1), (1285, 9216, 128, 0),
-                                       (25700, 1408, 256, 0)])
-def test_column_plans_give_the_bits_of_the_classic_tiling(M, N, K, epi):
-    """gemm9's column plans (round 4): for few tile rows the launcher cuts N into column tiles of 64 .. 256 columns, widest first, and
-    the persistent workgroups walk them in serpentine rounds, so that a rank's 25-sample shard (26 tile rows) keeps all 256 CUs busy.
-    Every element keeps its K order, so every plan -- the model's choice (gemm_plan 1), the best plan (2) and the forced 64- / 128- /
-    192-column tilings (11 / 12 / 13: the narrow tile bodies, duplicate B requests, partial last tiles) -- must give the bits of the
-    phased kernel, launch after launch with competing traffic (a plan changes which requests are in flight around a tile boundary)."""
-    L = cg.lib()
-    g = torch.Generator(device=DEV).manual_seed(M * 7 + N * 3 + K)
-    A = torch.zeros(ru(M, 256), K, device=DEV, dtype=torch.float16); A[:M] = (torch.randn(M, K, device=DEV, generator=g) * 0.5).half()
-    W = torch.zeros(ru(N, 256), K, device=DEV, dtype=torch.float16); W[:N] = (torch.randn(N, K, device=DEV, generator=g) * 0.05).half()
-    b = torch.randn(N, device=DEV, generator=g)
-    ld = ru(N, 8)
-    aux = torch.randn(M, ld, device=DEV, generator=g) if epi == 3 else None
-    dt = torch.float16 if epi < 2 else torch.float32
-    side = torch.cuda.Stream()
-    ja = torch.randn(4096, 4096, device=DEV, dtype=torch.float16)
-
-    def run(kernel, plan):
-        out = torch.full((M + 2, ld), 3.0, device=DEV, dtype=dt)              # 2 guard rows behind the matrix
-        _lib.check(L.cgpt_set_option(b"gemm_kernel", kernel))
-        _lib.check(L.cgpt_set_option(b"gemm_plan", plan))
-        _lib.check(L.cgpt_linear_f16(P(A), K, P(W), K, P(b), P(out), ld, P(aux) if aux is not None else None, ld, M, N, K, epi, stream()))
-        return out
-    try:
-        ref = run(4, 0)
-        assert torch.equal(run(14, 0), ref)
-        for plan in (1, 2, 11, 12, 13):
-            for it in range(3):
-                if it == 1:
-                    with torch.cuda.stream(side):
-                        ja @ ja
-                got = run(14, plan)
-                assert torch.equal(got, ref), (plan, it, int((got != ref).sum()))
-    finally:
-        _lib.check(L.cgpt_set_option(b"gemm_kernel", 0))
-        _lib.check(L.cgpt_set_option(b"gemm_plan", 1))
-    torch.cuda.synchronize()
-    assert bool((ref[M:] == 3.0).all()) and bool((ref[:, N:] == 3.0).all())
