@@ -12,9 +12,9 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool LDS>
+template <bool LDS, bool DMA = false>
 __global__ __launch_bounds__(512) void mfma_loop(const f16x8* __restrict__ src, float* out, unsigned long long* clk, int iters) {
-    __shared__ __attribute__((aligned(16))) f16x8 lds[4096];                 // 64 KiB of operand-shaped data
+    __shared__ __attribute__((aligned(16))) f16x8 lds[DMA ? 8192 : 4096];    // 64 KiB of operand-shaped data (+ 64 KiB that the LDS-DMA requests fill)
     const int tid = threadIdx.x;
     if (LDS) { for (int i = tid; i < 4096; i += blockDim.x) lds[i] = src[(blockIdx.x * 4096 + i) & 0xFFFF]; __syncthreads(); }
     f16x8 a[4], b[4];
@@ -37,6 +37,14 @@ __global__ __launch_bounds__(512) void mfma_loop(const f16x8* __restrict__ src, 
                 b[2 * half + 1] = lds[(rd + 320) & 4095];
                 rd += 384;
             }
+            if (DMA) {                                                       // the GEMM's operand stream: 2 LDS-DMA requests of 1 KiB per 16 MFMAs (8 per 64),
+                const int wv = tid >> 6, slot = ((it + half) * 2) & 7;      // from an L2-resident buffer into the other half of LDS; never waited for
+                const f16x8* g0 = src + ((blockIdx.x * 64 + (it + half) * 131 + (tid & 63)) & 0xFFFF);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g0,
+                                                 (__attribute__((address_space(3))) void*)(lds + 4096 + wv * 512 + slot * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + 4096),
+                                                 (__attribute__((address_space(3))) void*)(lds + 4096 + wv * 512 + ((slot + 1) & 7) * 64), 16, 0, 0);
+            }
         }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -46,13 +54,13 @@ __global__ __launch_bounds__(512) void mfma_loop(const f16x8* __restrict__ src, 
     if (tid == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-template <bool LDS> void run(const char* name, int threads, const f16x8* src) {
+template <bool LDS, bool DMA = false> void run(const char* name, int threads, const f16x8* src) {
     float* out; unsigned long long* clk;
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&clk, 256 * 2 * 8);
     const int iters = 20000;                                                 // 320 000 MFMAs per wave
     const double flop = 256.0 * (threads / 64) * iters * 16.0 * (2.0 * 16 * 16 * 32);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto launch = [&] { hipLaunchKernelGGL(mfma_loop<LDS>, dim3(256), dim3(threads), 0, 0, src, out, clk, iters); };
+    auto launch = [&] { hipLaunchKernelGGL((mfma_loop<LDS, DMA>), dim3(256), dim3(threads), 0, 0, src, out, clk, iters); };
     launch(); hipDeviceSynchronize();
     hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
     float one; hipEventElapsedTime(&one, e0, e1);
@@ -84,6 +92,7 @@ int main() {
     for (int th : {256, 512}) {
         run<false>("MFMA only, random operands", th, dr);
         run<true>("MFMA + the GEMM's LDS fragment reads, random", th, dr);
+        run<true, true>("... + its LDS-DMA requests (8 KiB / 64 MFMAs)", th, dr);
         run<false>("MFMA only, zero operands", th, dz);
     }
     return 0;
