@@ -309,7 +309,7 @@ def main():
     # HBM-side traffic of the fc1 GEMM: rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled as the
     # MI355X guide prescribes for gfx950) cannot be collected from inside this process; the committed summary of the same
     # command under profiles/ is reported when it matches this configuration (batch), else null.
-    traffic, traffic_note = None, "no PMC summary for this configuration"
+    traffic, traffic_note, pmc_fc1 = None, "no PMC summary for this configuration", None
     FC1_KERNEL = "gemm9_f16_kernel<1>"                 # roofline.kernel as rocprofv3 names it
     try:
         import glob
@@ -333,6 +333,9 @@ def main():
         else:
             traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
             same = meta.get("libcgpt_sha256_16") == lib_sha
+            # MFMA busy fraction and shader clock of the same kernel in the profiled run: busy x clock / 2.4 GHz reproduces `frac`
+            pmc_fc1 = {"mfma_busy_frac": pm.get("mfma_busy_frac"), "clock_ghz": pm.get("clock_ghz"), "l2_hit_rate": pm.get("l2_hit_rate"),
+                       "source": rel, "same_build": same}
             traffic_note = ("bytes per launch of %s from %s, taken at commit %s (%s this run's libcgpt.so; rocprofv3 --pmc FETCH_SIZE / "
                             "WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted): read %.0f MB + "
                             "write %.0f MB vs algorithmic %.0f MB (A %.0f + W %.0f + out %.0f; full %d-sample batches)" % (
@@ -366,6 +369,18 @@ def main():
         torch.cuda.synchronize()
         barrier()
         single_ms = 1e3 * (time.perf_counter() - ts) / reps
+
+    # The yardstick beside the data-sheet peak: the dense fp16 MFMA rate THIS device sustains on random operands with nothing else
+    # running (cgpt_mfma_sustained: MFMA-only loop, ~2 s, clock settled first), measured after everything else, rank 0 of a 1-GPU run only.
+    sustained = None
+    if world == 1 and rank == 0 and headline and not os.environ.get("CGPT_BENCH_NO_SUSTAINED"):
+        import ctypes as C
+        tf, ghz = C.c_double(), C.c_double()
+        if cg.lib().cgpt_mfma_sustained(2.0, C.byref(tf), C.byref(ghz)) == 0:
+            sustained = {"mfma_only_tflops": tf.value, "clock_ghz": ghz.value,
+                         "note": "v_mfma_f32_16x16x32_f16 back to back from registers on random fp16 operands, no LDS, no memory: what this device "
+                                 "sustains when it does nothing but MFMAs (the 2 500 of the data sheet is 1 024 SIMDs x 1 024 FLOP/clk at 2.4 GHz); "
+                                 "measured in this run, after the timed region (profiles/r04/mfma_sustained.txt)"}
 
     gen_report = None
     if gen:
@@ -450,12 +465,16 @@ def main():
                          "flop_per_launch": fc1_flops / max(fc1_n, 1),
                          "all_gemms": {"achieved": all_tflops, "frac": all_tflops / MFMA_PEAK_TFLOPS, "launches": all_n,
                                        "total_ms": all_ms},
-                         "vit_gemms": by_kind},
+                         "vit_gemms": by_kind,
+                         "pmc": pmc_fc1, "device_sustained": sustained},
             "results_sample": [[int(l), float(r)] for l, r in results[-3:]],
             "single_image_certify_ms": single_ms,
             "single_image_certify_note": "one reference-shaped Smooth.certify(x, n0, n, alpha, batch_size=n0+n) per image, no grouping "
                                          "of images (the headline value sends groups of images through Smooth.certify_many)",
         }
+        if sustained:
+            sustained["frac_of_sustained"] = fc1_tflops / sustained["mfma_only_tflops"]
+            sustained["all_gemms_frac_of_sustained"] = all_tflops / sustained["mfma_only_tflops"]
         if ranks_report is not None:
             line["ranks"] = ranks_report
         if not headline:

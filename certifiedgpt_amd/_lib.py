@@ -65,6 +65,7 @@ SIGNATURES = {
     "cgpt_binom_test": (_D, [_I64, _I64, _D]),
     "cgpt_norm_ppf": (_D, [_D]),
     "cgpt_set_option": (_I32, [C.c_char_p, _I32]),
+    "cgpt_mfma_sustained": (_I32, [_D, C.POINTER(_D), C.POINTER(_D)]),
     "cgpt_profile_enable": (_I32, [_P, _I32]),
     "cgpt_profile_read": (_I32, [_P, _I32, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I64)]),
     "cgpt_gemm_f16": (_I32, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),

@@ -115,4 +115,7 @@ hipError_t launch_f32_to_f16(const float* src, int64_t lds, half_t* dst, int64_t
 hipError_t launch_f16_to_f32(const half_t* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols,
                              hipStream_t stream);
 
+// diag.hip: the dense fp16 MFMA rate this device sustains on random operands with nothing else running (synchronous diagnostic)
+hipError_t run_mfma_sustained(double seconds, double* tflops, double* clock_ghz);
+
 }  // namespace cgpt

@@ -866,6 +866,16 @@ cgpt_status cgpt_attention_f16(const void* Q_dev, int64_t ldq, const void* K_dev
     return CGPT_OK;
 }
 
+cgpt_status cgpt_mfma_sustained(double seconds, double* tflops_out, double* clock_ghz_out) {
+    if (!tflops_out || !clock_ghz_out || !(seconds > 0.0 && seconds <= 30.0))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_mfma_sustained: seconds must be in (0, 30], outputs non-null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return cgpt_fail(CGPT_ERR_NO_DEVICE, "cgpt_mfma_sustained: no HIP device");
+    hipError_t e = run_mfma_sustained(seconds, tflops_out, clock_ghz_out);
+    if (e != hipSuccess) return cgpt_fail(CGPT_ERR_HIP, std::string("cgpt_mfma_sustained: ") + hipGetErrorString(e));
+    return CGPT_OK;
+}
+
 cgpt_status cgpt_layernorm(const float* x_dev, int64_t ldx, const float* gamma_dev, const float* beta_dev, float eps,
                            void* y_dev, int64_t ldy, float* y32_dev, int64_t ldy32, int64_t rows, int32_t D, void* stream) {
     if (!x_dev || !gamma_dev || !beta_dev || (!y_dev && !y32_dev)) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_layernorm: null argument");

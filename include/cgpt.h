@@ -226,6 +226,12 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
  * timing-study switches that skip work; profiles/r01/gemm_variants.txt.) */
 cgpt_status cgpt_set_option(const char* key, int32_t value);
 
+/* Measurement aid (no counterpart in the reference): the dense fp16 MFMA rate THIS device sustains on random operands when it does nothing
+ * else -- v_mfma_f32_16x16x32_f16 back to back from registers for `seconds` (clock settled first), in TFLOP/s, and the in-kernel shader
+ * clock in GHz.  The data sheet's 2.5 PFLOP/s assumes 2.4 GHz; under an MFMA-dense load an MI355X holds 1.8-1.95 GHz, so bench.py reports
+ * a kernel's fraction of the data-sheet peak AND of this rate (profiles/r04/mfma_sustained.txt).  Synchronous; uses the default stream. */
+cgpt_status cgpt_mfma_sustained(double seconds, double* tflops_out, double* clock_ghz_out);
+
 /* ---- raw kernels exported for unit tests and reuse (all fp16 operands are IEEE binary16) ----
  * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) ; A row stride lda, W row stride ldw (elements), fp32 accumulate.
  * Requirements: A must be readable for ceil(M/256)*256 rows and W for ceil(N/256)*256 rows (zero padded; the

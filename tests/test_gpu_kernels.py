@@ -420,3 +420,18 @@ def test_gelu_epilogue_gives_the_same_bits_on_every_kernel_under_load(M, N, K):
     err = (ref[rows].float() - want).abs()
     tol = 1e-3 * want.abs() + 2e-4            # fp16 rounding (2^-11 relative) + accumulation-order noise of the fp32 linear
     assert bool((err <= tol).all()), float((err / tol).max())
+
+
+def test_mfma_sustained_diagnostic_reports_a_plausible_rate():
+    """cgpt_mfma_sustained (the yardstick bench.py prints beside the data-sheet peak): an MFMA-only loop on random operands.  The rate
+    must lie between what a badly throttled device would give and the data sheet's 2.5 PFLOP/s, and equal 1 024 SIMDs x 16 384 FLOP /
+    ~16-17 cycles at the clock it reports (the matrix pipe never idles in that loop)."""
+    import ctypes as C
+    L = cg.lib()
+    tf, ghz = C.c_double(), C.c_double()
+    _lib.check(L.cgpt_mfma_sustained(0.5, C.byref(tf), C.byref(ghz)))
+    assert 900.0 < tf.value < 2600.0, tf.value
+    assert 1.0 < ghz.value < 2.6, ghz.value
+    cycles_per_mfma = ghz.value * 1e9 * 1024 * 16384 / (tf.value * 1e12)
+    assert 15.5 < cycles_per_mfma < 19.0, (cycles_per_mfma, tf.value, ghz.value)
+    assert L.cgpt_mfma_sustained(0.0, C.byref(tf), C.byref(ghz)) != 0
