@@ -48,39 +48,39 @@ __global__ __launch_bounds__(512) void mfma_sustained_kernel(float* out, unsigne
 hipError_t run_mfma_sustained(double seconds, double* tflops, double* clock_ghz) {
     int dev = 0, cus = 256;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
     float* out = nullptr;
     unsigned long long* clk = nullptr;
     if (hipError_t e = hipMalloc(&out, (size_t)cus * 512 * sizeof(float)); e != hipSuccess) return e;
-    if (hipError_t e = hipMalloc(&clk, (size_t)cus * 2 * sizeof(unsigned long long)); e != hipSuccess) { hipFree(out); return e; }
+    if (hipError_t e = hipMalloc(&clk, (size_t)cus * 2 * sizeof(unsigned long long)); e != hipSuccess) { (void)hipFree(out); return e; }
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int iters = 20000;                                                // 16 MFMAs per iteration and wave: ~3 ms per launch
     const double flop = (double)cus * 8.0 * iters * 16.0 * (2.0 * 16 * 16 * 32);
     auto launch = [&] { hipLaunchKernelGGL(mfma_sustained_kernel, dim3(cus), dim3(512), 0, 0, out, clk, iters, 12345u); };
     launch();
-    hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+    (void)hipEventRecord(e0); launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float one = 1.f;
-    hipEventElapsedTime(&one, e0, e1);
+    (void)hipEventElapsedTime(&one, e0, e1);
     if (one <= 0.f) one = 1.f;
     if (seconds < 0.2) seconds = 0.2;
     const int warm = (int)(seconds * 750.0 / one) + 1, timed = (int)(seconds * 250.0 / one) + 1;
     for (int i = 0; i < warm; ++i) launch();
-    hipEventRecord(e0);
+    (void)hipEventRecord(e0);
     for (int i = 0; i < timed; ++i) launch();
-    hipEventRecord(e1);
+    (void)hipEventRecord(e1);
     hipError_t err = hipEventSynchronize(e1);
     float ms = 1.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h((size_t)cus * 2);
     if (err == hipSuccess) err = hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double cyc = 0, real = 0;
     for (int i = 0; i < cus; ++i) { cyc += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
     if (tflops) *tflops = flop * timed / (ms * 1e-3) / 1e12;
     if (clock_ghz) *clock_ghz = real > 0 ? cyc / real * 0.1 : 0.0;
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(out); hipFree(clk);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(out); (void)hipFree(clk);
     return err;
 }
 
