@@ -57,7 +57,7 @@ template <int DPAD> __device__ __forceinline__ int k_chunk_pos(int row, int ch) 
 #endif
 
 // HD: head_dim (88 | 64); DPAD: HD rounded up to 32; NKT: 16-key tiles held (keys padded to NKT*16); NT: threads.
-template <int HD, int DPAD, int NKT, int NT, bool SLOT = false>
+template <int HD, int DPAD, int NKT, int NT>
 __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int KROW = AttnLayout<DPAD>::KROW, VSTR = AttnLayout<DPAD>::VSTR;
@@ -97,11 +97,9 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         const int hh = item_h(item), bb = item_b(item);
         const half_t* G = (want_v ? p.V : p.K) + (int64_t)bb * p.kv_batch_stride + hh * HD;
         const int ldg = (int)p.ldk;
-        int tid_r = tid;
-        if constexpr (SLOT) asm volatile("" : "+v"(tid_r));   // slot schedule: offsets recomputed per request, not kept (and spilled) across the item
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
-            const int idx = tid_r + it * NT;
+            const int idx = tid + it * NT;
             const int row = min(idx / CH, p.Tk - 1), ch = min(idx % CH, HD / 8 - 1);
             sreg[it] = *reinterpret_cast<const f16x8*>(G + (row * ldg + ch * 8));
         }
@@ -133,8 +131,8 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         for (int ds = 0; ds < NDS; ++ds) qf[ds] = (ds * 32 + g * 8 < HD) ? qnext[ds] : zero8;
     };
 
-    // S^T = K . Q^T for the query tile in qf -> s[] (MFMA + K fragment reads only).
-    auto qk = [&]() {
+    // S^T = K . Q^T for the query tile in qf, then the softmax numerators in s[] and the row sums in `sum`.
+    auto qk_softmax = [&]() {
         // K fragments do not depend on the query tile: an opaque zero keeps the compiler from hoisting them out of the loop
         int opq = 0;
         asm volatile("" : "+v"(opq));
@@ -165,11 +163,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
             s[kt] = acc;
             CGPT_FENCE
         }
-    };
-    // softmax numerators over the keys of s[] (all keys of a query: this lane's registers x the 4 lanes sharing r15), row sums in `sum`
-    auto softmax = [&]() {
-        int opq = 0;
-        asm volatile("" : "+v"(opq));
+        // softmax over keys (all keys of a query: this lane's registers x the 4 lanes sharing r15)
         float mx = -1e30f;
         const int klim = p.Tk - 4 * g + opq;          // key (kt*16 + 4g + r) is padding iff kt*16 + r >= klim
 #pragma unroll
@@ -201,17 +195,6 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         }
     };
 
-    // slot schedule: the fp16 P fragments of the tile whose softmax is done (its P.V runs one phase later, beside the next QK^T)
-    f16x8 pfk[SLOT ? NKT / 2 : 1];
-    auto pack_p = [&]() {
-#pragma unroll
-        for (int u = 0; u < NKT / 2; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pfk[SLOT ? u : 0][j] = (half_t)s[2 * u][j];
-                pfk[SLOT ? u : 0][4 + j] = (half_t)s[2 * u + 1][j];
-            }
-    };
     // O = P . V for query tile qt from s[] / sum, normalised and stored.
     auto pv_store = [&](int qt) {
         int opq = 0;
@@ -238,13 +221,10 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
             if (u + VD < NU) vload(u + VD, (u + VD) % (VD + 1));
             CGPT_FENCE
             f16x8 pf;
-            if constexpr (SLOT) pf = pfk[u];
-            else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    pf[j] = (half_t)s[2 * u][j];
-                    pf[4 + j] = (half_t)s[2 * u + 1][j];
-                }
+            for (int j = 0; j < 4; ++j) {
+                pf[j] = (half_t)s[2 * u][j];
+                pf[4 + j] = (half_t)s[2 * u + 1][j];
             }
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
@@ -261,9 +241,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
             den = __shfl(o[DT][RR], 16 * GG + r15);
         }
         const float inv = 1.0f / den;
-        int r15o = r15;
-        if constexpr (SLOT) asm volatile("" : "+v"(r15o));   // slot schedule: a wave's tiles are the same for every item, so the store offsets
-        const int q = qt * 16 + r15o;                          // would be hoisted out of the item loop (and spilled); recompute them here
+        const int q = qt * 16 + r15;
         // A lane owns d = 16 dt + 4g .. +3 of its query: 8 bytes per d-tile, a store instruction would write 16 rows x 32 B.
         // v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another: applied to the
         // packed fp16 results of two d-tiles (a, b) it leaves lane g with 8 CONSECUTIVE d -- 16 (g&1 ? b : a) + 8 (g>>1) .. +7 --
@@ -281,9 +259,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 packed = {s0[0], s1[0], s0[1], s1[1]};           // [new a | new b] = 8 consecutive halfs
             const int d0 = ((g & 1) ? db : da) * 16 + (g >> 1) * 8;
-            // (32-bit row offset inside a sample -- launch_attention checks Tq * ldo < 2^30: the 64-bit product was hoisted out of the item
-            // loop and, in the slot schedule, spilled; its scratch reload in front of every store waited for all loads in flight)
-            if (q < p.Tq && d0 < HD) *reinterpret_cast<u32x4*>(Ob + (q * (int)p.ldo + d0)) = packed;
+            if (q < p.Tq && d0 < HD) *reinterpret_cast<u32x4*>(Ob + (int64_t)q * p.ldo + d0) = packed;
         }
     };
 
@@ -294,97 +270,6 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
 #else
 #define CGPT_ASTAMP(k)
 #endif
-    // ---- slot schedule (SLOT, 8 waves): the two waves of a SIMD (w, w + 4) ran every tile in lock-step -- both in QK^T, both in the
-    // softmax, both in P.V -- so the SIMD did the matrix work of two tiles, then the vector work of two tiles (in-kernel stamps, round 4:
-    // a tile costs a wave 7.7 k cycles, two waves on a SIMD finish two tiles in the same 7.7 k, one wave alone takes 7 k).  Here a wave
-    // alternates a MATRIX phase (P.V of its previous tile, then QK^T of its next one: 108 MFMAs + their fragment reads) with a VECTOR
-    // phase (the softmax of that tile: max, exp2, fp16 packing), the late half (waves 4-7) runs one barrier-delimited slot behind the
-    // early half, and so every SIMD has one wave in its matrix phase and one in its vector phase at any time.
-    if constexpr (SLOT) {
-        static_assert(NT == 512 && NKT % 2 == 0, "slot schedule: 8 waves");
-        // Written out for 17 .. 24 query tiles (three rounds: tiles wave, wave + 8, wave + 16; the launcher sends other shapes to the
-        // classic walk): straight-line code per half, so that register liveness is exact -- a loop over slots with run-time phases made
-        // the compiler keep the scores AND the packed P of different tiles alive together (61 spills).
-        const bool late = wave >= 4;
-        const int t0 = wave, t1 = wave + NWAVES, t2 = wave + 2 * NWAVES;
-        const bool v2 = t2 < nqt;                                           // only the third tile may be missing
-        const bool eight_slots = nqt > 2 * NWAVES + 4;                      // a late wave has a third tile: one more slot
-        auto slot_barrier = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            CGPT_FENCE __builtin_amdgcn_s_barrier(); CGPT_FENCE
-        };
-        int item = blockIdx.x;
-        if (item_valid(item)) {
-            request_kv(item, false);
-            request_q_from(q_base_of(item), wave);
-        }
-        for (; item_valid(item); item += gridDim.x) {
-            const int h = item_h(item), b = item_b(item);
-            Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
-            Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
-            // K of this item: registers -> swizzled LDS image.  (tid_o: the thread id behind an opaque copy, so that the per-piece row /
-            // chunk / address arithmetic is redone here instead of being hoisted out of the item loop -- 35 hoisted registers were spilled,
-            // and a scratch reload is a vector load whose wait drains the K / V / Q requests in flight)
-            int tid_o = tid;
-            asm volatile("" : "+v"(tid_o));
-#pragma unroll
-            for (int it = 0; it < NV; ++it) {
-                const int idx = tid_o + it * NT;
-                const int row = idx / CH, ch = idx - row * CH;
-                const bool valid = row < p.Tk && ch * 8 < HD;
-                if (idx < TKP * CH) *reinterpret_cast<f16x8*>(Ks + row * KROW + k_chunk_pos<DPAD>(row, ch) * 8) = valid ? sreg[it] : zero8;
-            }
-            slot_barrier();
-            request_kv(item, true);                          // V of this item: written to LDS at the end of slot 1, first read in slot 2
-            const bool more_items = item_valid(item + (int)gridDim.x);
-            auto request_following = [&](int cur) {
-                if (cur + NWAVES < nqt) request_q(cur + NWAVES);
-                else if (more_items) request_q_from(q_base_of(item + gridDim.x), wave);
-            };
-            // (macros, not lambdas over lambdas: a closure that captures other closures by reference keeps the register arrays in scratch)
-#define CGPT_MATRIX_QK(t) { take_q(); request_following(t); qk(); }
-#define CGPT_VECTOR_PHASE { softmax(); pack_p(); }
-            auto stage_v = [&]() {                           // V: registers -> LDS (its loads have had slots 0 and 1 to land); then the NEXT item's K
-                int tid_v = tid;
-                asm volatile("" : "+v"(tid_v));
-#pragma unroll
-                for (int it = 0; it < NV; ++it) {
-                    const int idx = tid_v + it * NT;
-                    const int row = idx / CH, ch = idx - row * CH;
-                    const bool valid = row < p.Tk && ch * 8 < HD;
-                    f16x8 vv = valid ? sreg[it] : zero8;
-                    if (DPAD > HD && ch * 8 == HD) vv = f16x8{(half_t)1.0f, 0, 0, 0, 0, 0, 0, 0};   // ones column: row HD of O^T = softmax denominator
-                    if (idx < TKP * CH) *reinterpret_cast<f16x8*>(Vs + row * VSTR + ch * 8) = vv;
-                }
-            };
-            // the NEXT item's K is requested into the staging registers two slots before the item ends, at the start of a vector phase:
-            // held from slot 1 on they were live through the matrix phases (P.V + QK^T: the register peak) and got spilled
-            auto request_next_k = [&]() { if (more_items) request_kv(item + gridDim.x, false); };
-            if (!late) {
-                CGPT_MATRIX_QK(t0)                                                   slot_barrier();   // slot 0
-                CGPT_VECTOR_PHASE stage_v();                                       slot_barrier();   // slot 1
-                pv_store(t0); CGPT_MATRIX_QK(t1)                                     slot_barrier();   // slot 2
-                CGPT_VECTOR_PHASE                                                  slot_barrier();   // slot 3
-                pv_store(t1); if (v2) CGPT_MATRIX_QK(t2)                             slot_barrier();   // slot 4
-                request_next_k(); if (v2) CGPT_VECTOR_PHASE                        slot_barrier();   // slot 5
-                if (v2) pv_store(t2);                                            slot_barrier();   // slot 6
-                if (eight_slots) slot_barrier();                                                   // slot 7
-            } else {
-                                                                                 slot_barrier();   // slot 0
-                CGPT_MATRIX_QK(t0) stage_v();                                        slot_barrier();   // slot 1
-                CGPT_VECTOR_PHASE                                                  slot_barrier();   // slot 2
-                pv_store(t0); CGPT_MATRIX_QK(t1)                                     slot_barrier();   // slot 3
-                request_next_k(); CGPT_VECTOR_PHASE                                slot_barrier();   // slot 4
-                pv_store(t1); if (v2) CGPT_MATRIX_QK(t2)                             slot_barrier();   // slot 5
-                if (v2) CGPT_VECTOR_PHASE                                          slot_barrier();   // slot 6
-                if (eight_slots) { if (v2) pv_store(t2); slot_barrier(); }                         // slot 7
-            }
-#undef CGPT_MATRIX_QK
-#undef CGPT_VECTOR_PHASE
-        }
-        return;
-    }
-
     // ---- persistent walk over (sample, head) items
     int item = blockIdx.x;
     if (item_valid(item)) {
@@ -423,8 +308,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         if (have) {
             take_q();
             request_following(qt);
-            qk();
-            softmax();
+            qk_softmax();
         }
         CGPT_ASTAMP(1)                                   // first QK^T + softmax
 #pragma unroll
@@ -447,8 +331,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         for (qt += NWAVES; qt < nqt; qt += NWAVES) {
             take_q();
             request_following(qt);
-            qk();
-            softmax();
+            qk_softmax();
             pv_store(qt);
         }
         CGPT_ASTAMP(4)                                   // remaining query tiles of this wave
@@ -847,9 +730,7 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                     const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
                     const u32x4 packed = {s0[0], s1[0], s0[1], s1[1]};
                     const int d0 = ((g & 1) ? db : da) * 16 + (g >> 1) * 8;
-                    // (32-bit row offset inside a sample -- launch_attention checks Tq * ldo < 2^30: the 64-bit product was hoisted out of the item
-            // loop and, in the slot schedule, spilled; its scratch reload in front of every store waited for all loads in flight)
-            if (q < p.Tq && d0 < HD) *reinterpret_cast<u32x4*>(Ob + (q * (int)p.ldo + d0)) = packed;
+                    if (q < p.Tq && d0 < HD) *reinterpret_cast<u32x4*>(Ob + (int64_t)q * p.ldo + d0) = packed;
                 }
             }
         }
@@ -900,50 +781,39 @@ hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
 
 #undef CGPT_FENCE
 
-template <int HD, int DPAD, int NKT, int NT, bool SLOT = false>
+template <int HD, int DPAD, int NKT, int NT>
 hipError_t launch_one(const AttnParams& p, hipStream_t stream) {
     constexpr int lds_bytes = NKT * 16 * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
     int dev = 0, num_cus = 0;
     if (hipError_t e = device_cus(dev, num_cus); e != hipSuccess) return e;
     static bool configured[kMaxDevicesA] = {false};
     if (!configured[dev]) {
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, DPAD, NKT, NT, SLOT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, DPAD, NKT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             e != hipSuccess) return e;
         configured[dev] = true;
     }
     const int items = p.heads * p.B;
     const int per_cu = lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 40 * 1024 ? 2 : 4);     // resident workgroups per CU (LDS)
     const int grid = items < num_cus * per_cu ? items : num_cus * per_cu;
-    hipLaunchKernelGGL((attention_kernel<HD, DPAD, NKT, NT, SLOT>), dim3(grid), dim3(NT), lds_bytes, stream, p);
+    hipLaunchKernelGGL((attention_kernel<HD, DPAD, NKT, NT>), dim3(grid), dim3(NT), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
 }  // namespace
-
-int g_attn_slot = 1;   // resident 8-wave kernel: 1 = slot schedule (matrix / vector phases of SIMD partners alternate), 0 = classic walk
 
 hipError_t launch_attention(const AttnParams& p_in, hipStream_t stream) {
     AttnParams p = p_in;
     p.dbg = g_gemm_dbg;                             // diagnostic stamp buffer (null outside -DCGPT_STAMPS experiments)
     if (p.B <= 0 || p.heads <= 0 || p.Tq <= 0 || p.Tk <= 0) return hipErrorInvalidValue;
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 8)) return hipErrorInvalidValue;   // 16-byte row alignment
-    if (p.ldk != p.ldv || p.Tk * p.ldk >= (1ll << 30) || p.Tq * p.ldq >= (1ll << 30) || p.Tq * p.ldo >= (1ll << 30))
-        return hipErrorInvalidValue;                                                                                  // 32-bit offsets within a sample
+    if (p.ldk != p.ldv || p.Tk * p.ldk >= (1ll << 30) || p.Tq * p.ldq >= (1ll << 30)) return hipErrorInvalidValue;   // 32-bit offsets within a sample
     const bool small = p.Tk <= 32;
-#ifndef CGPT_ATT_STREAM_MIN_TK
-#define CGPT_ATT_STREAM_MIN_TK 288  // experiment builds: 0 = the streaming kernel for every shape
-#endif
-    if (p.Tk > CGPT_ATT_STREAM_MIN_TK) {            // K/V streamed through LDS in 192-key chunks (448^2 images)
+    if (p.Tk > 288) {                               // K/V streamed through LDS in 192-key chunks (448^2 images)
         if (p.head_dim == 88) return launch_stream<88, 96, 192>(p, stream);
         if (p.head_dim == 64) return launch_stream<64, 64, 192>(p, stream);
         return hipErrorInvalidValue;
     }
-#ifndef CGPT_ATT_NT
-#define CGPT_ATT_NT 512             // experiment builds: 256 = one wave per SIMD
-#endif
-    const int nqt = (p.Tq + 15) / 16;
-    if (p.head_dim == 88 && !small && g_attn_slot && nqt >= 17 && nqt <= 24) return launch_one<88, 96, 18, 512, true>(p, stream);
-    if (p.head_dim == 88) return small ? launch_one<88, 96, 2, 128>(p, stream) : launch_one<88, 96, 18, CGPT_ATT_NT>(p, stream);
+    if (p.head_dim == 88) return small ? launch_one<88, 96, 2, 128>(p, stream) : launch_one<88, 96, 18, 512>(p, stream);
     if (p.head_dim == 64) return small ? launch_one<64, 64, 2, 128>(p, stream) : launch_one<64, 64, 18, 512>(p, stream);
     return hipErrorInvalidValue;
 }
