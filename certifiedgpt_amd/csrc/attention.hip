@@ -348,271 +348,6 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
 }
 
 
-// ------------------------------------------------------------------------------------------- resident variant with LDS-DMA staging
-// Round-4 EXPERIMENT (profiles/r04/attention_slot_schedule.txt, section 5): the algorithm of attention_kernel for head_dim 88 and up to 272 keys
-// (T = 257) with K and V brought into LDS by LDS-DMA instead of through 28 staging registers and ds_writes:
-//   * LDS holds TWO K images (272 rows x 192 B, attention_kernel's chunk swizzle applied on the SOURCE side) and one V image (288 rows x 192 B,
-//     rows 272-287 stay zero): 159 744 B.  V's rows are 192 B instead of the 224-B stride, so the eight rows a 32-lane half reads by
-//     ds_read_b64_tr_b16 are kept on distinct 32-byte windows by a ROTATION: rows with bit 2 set store window w (d = 16 w .. 16 w + 15) at
-//     position (w + 1) mod 6 (192 r mod 256 repeats with period 4; the rotation moves rows 4-7 onto the odd windows: conflict-free).
-//   * top of item i: barrier (everybody's K(i) has landed, nobody reads V(i-1) / K(i-1) any more), V(i) requested; it lands under the first
-//     QK^T + softmax; behind the V barrier the NEXT item's K is requested into the other K image (requested together with V its 50 KB competed
-//     with the first QK^T's fragment reads: +8 %); a wave retires its requests in front of the stores of its last tile of the item.
-//     Pad slots (K chunk 11, V's ones column, rows >= Tk) are written once per kernel and skipped by the requests.
-// Bit-identical to attention_kernel, 215 VGPRs -- and exactly as fast (242 vs 239 us per 255-sample launch): staging was not what the item waits for.
-template <int HD, int DPAD>
-__global__ __launch_bounds__(512) void attention_dma_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NKT = 18, KROWS = 272, VROWS = 288, KROW = DPAD, VSTR = DPAD;
-    constexpr int CH = DPAD / 8, DC = HD / 8, NDS = DPAD / 32, NDT = DPAD / 16, NWAVES = 8, NWIN = DPAD / 16;
-    constexpr int KIMG = KROWS * KROW, VIMG = VROWS * VSTR;                   // halfs
-    constexpr int KREQ = KROWS * CH / 64, VREQ = VROWS * CH / 64;             // 1-KiB requests per image
-    constexpr int NIK = (KREQ + 7) / 8, NIV = (VREQ + 7) / 8;
-    static_assert(HD == 88 && DPAD == 96 && KROWS * CH % 64 == 0 && VROWS * CH % 64 == 0, "ViT-G head shape");
-    half_t* const smem = reinterpret_cast<half_t*>(smem_raw);
-    half_t* const Vs = smem + 2 * KIMG;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r15 = lane & 15, g = lane >> 4;
-    const int nitems = p.heads * p.B;
-    const bool xcd_walk = (gridDim.x & 7) == 0 && p.B >= 64;                 // see attention_kernel
-    auto item_valid = [&](int it) { return xcd_walk ? ((it >> 3) / p.heads) * 8 + (it & 7) < p.B : it < nitems; };
-    auto item_b = [&](int it) { return xcd_walk ? ((it >> 3) / p.heads) * 8 + (it & 7) : it / p.heads; };
-    auto item_h = [&](int it) { return xcd_walk ? (it >> 3) % p.heads : it % p.heads; };
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    // every LDS byte is initialised once (pad slots are never written by the DMA; an over-read of key tile 17 must meet finite values), then
-    // the ones column of V: row < Tk, d = HD -> logical chunk DC, i.e. window 5, second half
-    for (int i = tid; i < (2 * KIMG + VIMG) / 8; i += 512) reinterpret_cast<f16x8*>(smem)[i] = zero8;
-    __syncthreads();
-    for (int row = tid; row < p.Tk && row < VROWS; row += 512) {
-        const int pw = (5 + ((row >> 2) & 1)) % NWIN;
-        f16x8 v = zero8;
-        v[0] = (half_t)1.0f;
-        *reinterpret_cast<f16x8*>(Vs + row * VSTR + pw * 16 + 8) = v;
-    }
-
-    // slot -> (row, source chunk) of this lane's piece of request r = wave + 8 i (does not depend on the item); chunk >= DC: pad slot
-    int krc[NIK], vrc[NIV];
-#pragma unroll
-    for (int i = 0; i < NIK; ++i) {
-        const int slot = (wave + 8 * i) * 64 + lane, row = slot / CH;
-        krc[i] = row << 8 | k_chunk_pos<DPAD>(row, slot - row * CH);         // the swizzle is an involution
-    }
-#pragma unroll
-    for (int i = 0; i < NIV; ++i) {
-        const int slot = (wave + 8 * i) * 64 + lane, row = slot / CH, pos = slot - row * CH;
-        const int w = ((pos >> 1) + NWIN - ((row >> 2) & 1)) % NWIN;
-        vrc[i] = row << 8 | (2 * w + (pos & 1));
-    }
-    auto request_k = [&](int item, int buf) {
-        const half_t* G = p.K + (int64_t)item_b(item) * p.kv_batch_stride + item_h(item) * HD;
-        half_t* dst = smem + buf * KIMG;
-#pragma unroll
-        for (int i = 0; i < NIK; ++i) {
-            const int r = wave + 8 * i, row = krc[i] >> 8, ch = krc[i] & 255;
-            if (r < KREQ && ch < DC && row < p.Tk)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(G + (row * (int)p.ldk + ch * 8)),
-                                                 (__attribute__((address_space(3))) void*)(dst + r * 512), 16, 0, 0);
-        }
-    };
-    auto request_v = [&](int item) {
-        const half_t* G = p.V + (int64_t)item_b(item) * p.kv_batch_stride + item_h(item) * HD;
-#pragma unroll
-        for (int i = 0; i < NIV; ++i) {
-            const int r = wave + 8 * i, row = vrc[i] >> 8, ch = vrc[i] & 255;
-            if (r < VREQ && ch < DC && row < p.Tk)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(G + (row * (int)p.ldv + ch * 8)),
-                                                 (__attribute__((address_space(3))) void*)(Vs + r * 512), 16, 0, 0);
-        }
-    };
-
-    const float sl2 = p.scale * 1.44269504088896340736f;
-    const int nqt = (p.Tq + 15) >> 4;
-    const half_t* Qb = nullptr;
-    half_t* Ob = nullptr;
-    const half_t* Ks = smem;
-    f32x4 s[NKT];
-    f16x8 qf[NDS], qnext[NDS];
-    auto request_q_from = [&](const half_t* qbase, int qt) {
-        int el;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
-        const int qoff = min(qt * 16 + (el & 15), p.Tq - 1) * (int)p.ldq;
-#pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) {
-            const int d = min(ds * 32 + (el >> 4) * 8, HD - 8);
-            qnext[ds] = *reinterpret_cast<const f16x8*>(qbase + (qoff + d));
-        }
-    };
-    auto q_base_of = [&](int it) { return p.Q + (int64_t)item_b(it) * p.q_batch_stride + item_h(it) * HD; };
-    auto take_q = [&]() {
-#pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) qf[ds] = (ds * 32 + g * 8 < HD) ? qnext[ds] : zero8;
-    };
-    auto qk_softmax = [&]() {
-        int opq = 0;
-        asm volatile("" : "+v"(opq));
-        const half_t* Kq = Ks + opq;
-        auto kaddr = [&](int kt, int ds) {
-            const int row = kt * 16 + r15;
-            return Kq + row * KROW + k_chunk_pos<DPAD>(row, ds * 4 + g) * 8;
-        };
-#ifndef CGPT_ATT_DMA_KD
-#define CGPT_ATT_DMA_KD 2
-#endif
-        constexpr int KD = CGPT_ATT_DMA_KD;                            // key tiles in flight ahead of the MFMAs (3, 4: no change)
-        f16x8 kring[KD + 1][NDS];
-#pragma unroll
-        for (int kt = 0; kt < KD; ++kt)
-#pragma unroll
-            for (int ds = 0; ds < NDS; ++ds) kring[kt % (KD + 1)][ds] = *reinterpret_cast<const f16x8*>(kaddr(kt, ds));
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            if (kt + KD < NKT) {
-#pragma unroll
-                for (int ds = 0; ds < NDS; ++ds)
-                    kring[(kt + KD) % (KD + 1)][ds] = *reinterpret_cast<const f16x8*>(kaddr(kt + KD, ds));
-            }
-            CGPT_FENCE
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ds = 0; ds < NDS; ++ds)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kring[kt % (KD + 1)][ds], qf[ds], acc, 0, 0, 0);
-            s[kt] = acc;
-            CGPT_FENCE
-        }
-        float mx = -1e30f;
-        const int klim = p.Tk - 4 * g + opq;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            if (kt * 16 + 16 > p.Tk) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kt * 16 + r >= klim) s[kt][r] = -1e30f;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mxs = mx * sl2;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, -mxs));
-    };
-    // drain: the wave's LAST tile of the item -- behind its MFMAs and in front of its stores everything requested earlier has landed
-    // (the next item's K among it, a tile or more old by then); the stores and the Q request of the next item come after and stay in flight
-    auto pv_store = [&](int qt, bool drain) {
-        int opq = 0;
-        asm volatile("" : "+v"(opq));
-        // lane (r15, g) supplies row 4g + (r15 >> 2) (+ 32 u, + 16), columns 16 dt + 4 (r15 & 3) .. +3; rows with bit 2 set -- odd g for every
-        // block this lane reads -- keep window dt at position (dt + 1) mod 6
-        const half_t* vrow = Vs + opq + (4 * g + (r15 >> 2)) * VSTR + 4 * (r15 & 3);
-        const half_t* vbaseA = vrow + (g & 1) * 16;                        // windows 0 .. 4 at + 16 dt
-        const half_t* vbase5 = vrow + ((g & 1) ? 0 : 80);                  // window 5
-        f32x4 o[NDT];
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int NU = NKT / 2;
-        f16x4 vring[2][NDT][2];
-        auto vload = [&](int u, int slot) {
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const half_t* a1 = (dt < NDT - 1 ? vbaseA + dt * 16 : vbase5) + (32 * u) * VSTR;
-                vring[slot][dt][0] = lds_read_tr16(a1);
-                vring[slot][dt][1] = lds_read_tr16(a1 + 16 * VSTR);
-            }
-        };
-        vload(0, 0);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            if (u + 1 < NU) vload(u + 1, (u + 1) & 1);
-            CGPT_FENCE
-            f16x8 pf;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pf[j] = (half_t)s[2 * u][j];
-                pf[4 + j] = (half_t)s[2 * u + 1][j];
-            }
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const f16x4 v1 = vring[u & 1][dt][0], v2 = vring[u & 1][dt][1];
-                const f16x8 vf = {v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
-            }
-            CGPT_FENCE
-        }
-        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        constexpr int DT = HD / 16, GG = (HD % 16) / 4, RR = (HD % 16) % 4;   // row HD of O^T = the softmax denominator (ones column of V)
-        const float inv = 1.0f / __shfl(o[DT][RR], 16 * GG + r15);
-        const int q = qt * 16 + r15;
-#pragma unroll
-        for (int dp = 0; dp < NDT / 2; ++dp) {
-            const int da = 2 * dp, db = 2 * dp + 1;
-            const f16x4 ha = {(half_t)(o[da][0] * inv), (half_t)(o[da][1] * inv), (half_t)(o[da][2] * inv), (half_t)(o[da][3] * inv)};
-            const f16x4 hb = {(half_t)(o[db][0] * inv), (half_t)(o[db][1] * inv), (half_t)(o[db][2] * inv), (half_t)(o[db][3] * inv)};
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 ua = __builtin_bit_cast(u32x2, ha), ub = __builtin_bit_cast(u32x2, hb);
-            const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 packed = {s0[0], s1[0], s0[1], s1[1]};
-            const int d0 = ((g & 1) ? db : da) * 16 + (g >> 1) * 8;
-            if (q < p.Tq && d0 < HD) *reinterpret_cast<u32x4*>(Ob + (int64_t)q * p.ldo + d0) = packed;
-        }
-    };
-    auto wg_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        CGPT_FENCE __builtin_amdgcn_s_barrier(); CGPT_FENCE
-    };
-
-    int item = blockIdx.x, kb = 0;
-    wg_barrier();                                        // LDS initialised before the first request may land
-    if (item_valid(item)) {
-        request_k(item, 0);
-        if (wave < nqt) request_q_from(q_base_of(item), wave);
-    }
-    for (; item_valid(item); item += gridDim.x, kb ^= 1) {
-        const int h = item_h(item), b = item_b(item);
-        Qb = p.Q + (int64_t)b * p.q_batch_stride + h * HD;
-        Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
-        Ks = smem + kb * KIMG;
-        const bool more_items = item_valid(item + (int)gridDim.x);
-        // this wave's pieces of K(item) were retired by the drain of its last tile of the previous item (first item, or no tile: here);
-        // behind the barrier everybody's have landed, and nobody reads the previous item's images any more.  (A wait HERE would also
-        // wait for the O stores issued a moment ago.)
-        if (item == (int)blockIdx.x || wave >= nqt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wg_barrier();
-        request_v(item);
-        auto request_following = [&](int cur) {
-            if (cur + NWAVES < nqt) request_q_from(Qb, cur + NWAVES);
-            else if (more_items) request_q_from(q_base_of(item + gridDim.x), wave);
-        };
-        int qt = wave;
-        const bool have = qt < nqt;
-        if (have) {
-            take_q();
-            request_following(qt);
-            qk_softmax();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of V(item) (requested a QK^T + softmax ago)
-        wg_barrier();
-        // the NEXT item's K goes to the other K image now, so that its 50 KB land under the remaining tiles instead of competing with V's for the
-        // first QK^T's fragment reads
-        if (more_items) request_k(item + gridDim.x, kb ^ 1);
-        if (have) pv_store(qt, qt + NWAVES >= nqt);
-        for (qt += NWAVES; qt < nqt; qt += NWAVES) {
-            take_q();
-            request_following(qt);
-            qk_softmax();
-            pv_store(qt, qt + NWAVES >= nqt);
-        }
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------- streaming variant
 // Tk > 288 (448^2 images: T = 1025, the reference's own image size, minigpt4.py:32; eva_vit.py:383-404): K and V no longer fit in
 // LDS, so a workgroup owns 256 queries of one (sample, head) and streams the keys through LDS with an online softmax.  With the
@@ -1026,22 +761,6 @@ inline hipError_t device_cus(int& dev, int& cus) {
     return hipSuccess;
 }
 
-hipError_t launch_dma(const AttnParams& p, hipStream_t stream) {
-    constexpr int lds_bytes = (2 * 272 + 288) * 96 * (int)sizeof(half_t);   // two K images + one V image = 159 744 B
-    int dev = 0, num_cus = 0;
-    if (hipError_t e = device_cus(dev, num_cus); e != hipSuccess) return e;
-    static bool configured[kMaxDevicesA] = {false};
-    if (!configured[dev]) {
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_dma_kernel<88, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            e != hipSuccess) return e;
-        configured[dev] = true;
-    }
-    const int items = p.heads * p.B;
-    const int grid = items < num_cus ? items : num_cus;
-    hipLaunchKernelGGL((attention_dma_kernel<88, 96>), dim3(grid), dim3(512), lds_bytes, stream, p);
-    return hipGetLastError();
-}
-
 template <int HD, int DPAD, int TKP>
 hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
     constexpr int lds_bytes = 2 * TKP * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
@@ -1082,8 +801,6 @@ hipError_t launch_one(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int g_attn_dma = 1;   // head_dim 88, 65..272 keys: 1 = K / V staged by LDS-DMA (attention_dma_kernel), 0 = register staging (attention_kernel)
-
 hipError_t launch_attention(const AttnParams& p_in, hipStream_t stream) {
     AttnParams p = p_in;
     p.dbg = g_gemm_dbg;                             // diagnostic stamp buffer (null outside -DCGPT_STAMPS experiments)
@@ -1096,7 +813,6 @@ hipError_t launch_attention(const AttnParams& p_in, hipStream_t stream) {
         if (p.head_dim == 64) return launch_stream<64, 64, 192>(p, stream);
         return hipErrorInvalidValue;
     }
-    if (p.head_dim == 88 && !small && p.Tk <= 272 && p.Tk > 64 && g_attn_dma) return launch_dma(p, stream);
     if (p.head_dim == 88) return small ? launch_one<88, 96, 2, 128>(p, stream) : launch_one<88, 96, 18, 512>(p, stream);
     if (p.head_dim == 64) return small ? launch_one<64, 64, 2, 128>(p, stream) : launch_one<64, 64, 18, 512>(p, stream);
     return hipErrorInvalidValue;

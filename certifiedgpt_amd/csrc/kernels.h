@@ -55,7 +55,6 @@ struct AttnParams {
     unsigned long long* dbg = nullptr;   // diagnostic builds only (-DCGPT_STAMPS): per-wave phase cycle sums
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
-extern int g_attn_dma;      // speed only (bit-identical): 1 = LDS-DMA staging for head_dim 88, 65..272 keys
 
 // --------------------------------------------------------------------------------------- LayerNorm
 // y = (x - mean) / sqrt(var + eps) * gamma + beta over D, fp32 statistics (base_model.py:281-287).

@@ -782,11 +782,6 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
         g_gemm_kernel = value;
         return CGPT_OK;
     }
-    if (k == "attn_dma") {
-        if (value != 0 && value != 1) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: attn_dma must be 0 or 1");
-        g_attn_dma = value;
-        return CGPT_OK;
-    }
     if (k == "gemm_ablate") {
 #ifndef CGPT_LAB
         if (value & ~(512 | 16384))

@@ -19,18 +19,10 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(10): f()
 e1.record(); torch.cuda.synchronize()
-# LDS-DMA staging (attn_dma 1) against register staging (0), interleaved rounds in one process
-res = {0: [], 1: []}
-outs = {}
+res = []
 for r in range(5):
-    for dma in (1, 0):
-        _lib.check(L.cgpt_set_option(b"attn_dma", dma))
-        out.zero_(); f(); torch.cuda.synchronize()
-        outs[dma] = out.clone()
-        e0.record()
-        for _ in range(10): f()
-        e1.record(); torch.cuda.synchronize()
-        res[dma].append(e0.elapsed_time(e1) / 10 * 1e3)
-_lib.check(L.cgpt_set_option(b"attn_dma", 1))
-print(f"attention B={B} T={T}: us per launch, LDS-DMA staging median {sorted(res[1])[2]:.1f} min {min(res[1]):.1f} | register staging median {sorted(res[0])[2]:.1f} min {min(res[0]):.1f}"
-      f" | outputs bit-identical: {bool(torch.equal(outs[0], outs[1]))}")
+    e0.record()
+    for _ in range(10): f()
+    e1.record(); torch.cuda.synchronize()
+    res.append(e0.elapsed_time(e1) / 10 * 1e3)
+print(f"attention B={B} T={T}: us per launch median {sorted(res)[2]:.1f} min {min(res):.1f}")
