@@ -166,15 +166,30 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
         // softmax over keys (all keys of a query: this lane's registers x the 4 lanes sharing r15)
         float mx = -1e30f;
         const int klim = p.Tk - 4 * g + opq;          // key (kt*16 + 4g + r) is padding iff kt*16 + r >= klim
+        // Only key tiles that reach past Tk need the padding mask.  hipcc turns a per-tile `if (kt * 16 + 16 > Tk)` into a compare + select
+        // per register of EVERY tile (72 + 72 VALU instructions per query tile, ~9 % of its vector issue: round 4's instruction count), so
+        // the common case -- at most the last two key tiles hold padding, Tk > 16 (NKT - 2): every ViT shape -- is a branch of its own.
+        constexpr int NFULL = NKT > 2 ? NKT - 2 : 0;
+        if (p.Tk >= NFULL * 16) {
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            if (kt * 16 + 16 > p.Tk) {                // wave-uniform: only the boundary tiles pay for the mask
+            for (int kt = 0; kt < NKT; ++kt) {
+                if (kt >= NFULL) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + r >= klim) s[kt][r] = -1e30f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (kt * 16 + r >= klim) s[kt][r] = -1e30f;
-            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
