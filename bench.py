@@ -370,6 +370,31 @@ def main():
         barrier()
         single_ms = 1e3 * (time.perf_counter() - ts) / reps
 
+    # SURVEY.md 8(e) asks for both partitions: the same timed images once more, IMAGE-sharded (Smooth.certify_images: every rank
+    # certifies whole images with all their draws, no vote all-reduce; 16 bytes per image come back).  Same sample indices as the
+    # timed region, so the (label, radius) list must be the same list.  Outside the timed region; reported beside the headline.
+    image_sharded = None
+    if world > 1 and not rgf and not gen:
+        sm2 = cg.Smooth(base, NUM_CLASSES, SIGMA, seed=42)
+        sm2.certify_images(images[:min(world, len(images))], n_sel, n_est, ALPHA, per_gpu)      # untimed: first use of this path
+        sm2.reset(args.warmup * (n_sel + n_est))                                             # the cursor of the timed region
+        torch.cuda.synchronize()
+        barrier()
+        ts = time.perf_counter()
+        out2 = sm2.certify_images(images[args.warmup:args.warmup + args.steps], n_sel, n_est, ALPHA, per_gpu)
+        torch.cuda.synchronize()
+        barrier()
+        t2 = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        el2 = float(t2.item())
+        image_sharded = {"value": args.steps / el2, "unit": "certified images/s", "ms_per_step": 1e3 * el2 / args.steps,
+                         "images_per_rank_max": -(-args.steps // world),
+                         "equals_sample_sharded": [(int(l), float(r)) for l, r in out2] ==
+                                                  [(int(l), float(r)) for l, r in results[args.warmup:]],
+                         "note": "the other partition of SURVEY.md 8(e): whole images per rank (all n0 + n draws of each), no vote "
+                                 "all-reduce, one 16-byte-per-image exchange of results; the timed region's images and sample indices, "
+                                 "barrier + synchronize on both sides, MAX over ranks; `value` above stays the sample-sharded mode"}
+
     # The yardstick beside the data-sheet peak: the dense fp16 MFMA rate THIS device sustains on random operands with nothing else
     # running (cgpt_mfma_sustained: MFMA-only loop, ~2 s, clock settled first), measured after everything else, rank 0 of a 1-GPU run only.
     sustained = None
@@ -477,6 +502,8 @@ def main():
             sustained["all_gemms_frac_of_sustained"] = all_tflops / sustained["mfma_only_tflops"]
         if ranks_report is not None:
             line["ranks"] = ranks_report
+        if image_sharded is not None:
+            line["image_sharded"] = image_sharded
         if not headline:
             T = (args.img_size // 14) ** 2 + 1
             what = (f"8-step RGF attack (1 direction per step) + smoothed predict, {attack.forwards_per_image(n_est)} forwards per image"

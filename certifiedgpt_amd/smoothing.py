@@ -7,7 +7,8 @@ conventions.  Differences, all build-side and documented in DESIGN.md:
     the HIP classifier, argmax and the vote histogram stay on the GPU; one device->host copy per `_sample_noise`
     instead of one per batch (smoothing.py:98);
   * with torch.distributed initialised, the sample range of every `_sample_noise` is sharded over the ranks and the
-    int64 histograms are summed with ONE all-reduce (RCCL over xGMI; gloo in CPU tests);
+    int64 histograms are summed with ONE all-reduce (RCCL over xGMI; gloo in CPU tests); `certify_images` is the other
+    partition SURVEY.md 8(e) names: whole images per rank, no vote collective, results exchanged at 16 bytes per image;
   * the statistics (smoothing.py:46-56,73-79,107-117) are float64 host functions of the C-ABI -- no scipy /
     statsmodels needed at run time.
 There is no CPU fallback: without libcgpt.so import fails, without a GPU the engine cannot be created.
@@ -178,6 +179,47 @@ class Smooth(object):
             self._all_reduce(counts)
         c = counts.cpu().numpy().astype(int)
         return [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(G)]
+
+    def certify_images(self, xs, n0: int, n: int, alpha: float, batch_size: int):
+        """`certify` for a stack of images xs[G,3,H,W], IMAGE-sharded (SURVEY.md 8(e), the zero-communication throughput mode;
+        launch.py:110-120 starts one process per device): rank r certifies images shard_range(G, r, world) with ALL n0 + n draws
+        of each -- no vote histogram leaves the rank -- and the G (label, radius) pairs, 16 bytes per image, are then summed
+        into every rank's copy of the result table (the only collective; on one rank there is none).  Image i draws the sample
+        indices the i-th of G consecutive `certify` calls would use, so the list equals that of `certify_many` and of the
+        one-by-one loop on any number of ranks (counts bit-identical, statistics the same float64 code)."""
+        G = int(xs.shape[0])
+        first = self._next_sample
+        self._next_sample += G * (n0 + n)
+        rank, world = _world(self.process_group)
+        lo, hi = shard_range(G, rank, world)
+        table = torch.zeros(G, 2, dtype=torch.float64, device=xs.device)
+        if hi > lo:
+            with torch.no_grad():
+                c = self._timed_compute(lambda: self._counts_of_images(xs[lo:hi], first + lo * (n0 + n), n0, n, batch_size))
+            c = c.cpu().numpy().astype(int)
+            mine = [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(hi - lo)]
+            table[lo:hi] = torch.tensor(mine, dtype=torch.float64).to(table.device)
+        if world > 1:
+            self._all_reduce(table)                        # rows of the other ranks are zero here: the SUM is a gather
+        t = table.cpu().numpy()
+        return [(int(t[i, 0]), float(t[i, 1])) for i in range(G)]
+
+    def _counts_of_images(self, xs, first: int, n0: int, n: int, batch_size) -> torch.Tensor:
+        """int64 [g, 2, K]: selection and estimation histograms of g images, every draw on THIS rank; image i uses the indices
+        first + i (n0 + n) ... (the cursor positions of consecutive `certify` calls)."""
+        bc = self.base_classifier
+        bc.eval()
+        g = int(xs.shape[0])
+        if hasattr(bc, "sample_counts_images") and g > 1:
+            return bc.sample_counts_images(xs, first, n0, first + n0, n, n0 + n, float(self.sigma), self.seed)
+        out = []
+        for i in range(g):
+            f = first + i * (n0 + n)
+            if hasattr(bc, "sample_counts_pair"):
+                out.append(bc.sample_counts_pair(xs[i], f, n0, f + n0, n, batch_size, float(self.sigma), self.seed))
+            else:
+                out.append(torch.stack([self._local_counts(xs[i], f, n0, batch_size), self._local_counts(xs[i], f + n0, n, batch_size)]))
+        return torch.stack(out)
 
     def sample_noise_many(self, xs, num: int, batch_size, common_noise: bool = True) -> np.ndarray:
         """`_sample_noise` for a stack of images -> int array [G, num_classes].  common_noise=True: every image sees the

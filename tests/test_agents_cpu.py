@@ -69,6 +69,30 @@ def test_grouped_certify_gives_the_same_records(tmp_path):
     assert outs[0] == outs[1] and len(outs[0]) == 3
 
 
+def test_image_sharded_mode_gives_the_same_records_and_bad_mode_is_refused(tmp_path):
+    """run.smoothing.shard = images routes through Smooth.certify_images (whole images per rank; one rank here): the log
+    equals the one-by-one loop's.  An unknown mode is an error, not a silent default."""
+    outs = []
+    for shard in ("samples", "images"):
+        cfg = _config(tmp_path / shard, "image_text_certify")
+        cfg["run"]["smoothing"].update(images_per_pass=2, shard=shard)
+        registry.register("configuration", cfg)
+        agent = setup_agent(cfg)
+        agent.classifier = Engine()
+        agent.dataset = [(torch.zeros(3, 8, 8), 2), (torch.zeros(3, 8, 8), 1), (torch.zeros(3, 8, 8), 2)]
+        agent.run()
+        outs.append([(r["idx"], r["label"], r["predict"], r["radius"]) for r in agent.records])
+    assert outs[0] == outs[1] and len(outs[0]) == 3
+    cfg = _config(tmp_path / "bad", "image_text_certify")
+    cfg["run"]["smoothing"]["shard"] = "pixels"
+    registry.register("configuration", cfg)
+    agent = setup_agent(cfg)
+    agent.classifier = Engine()
+    agent.dataset = [(torch.zeros(3, 8, 8), 2)]
+    with pytest.raises(ValueError):
+        agent.run()
+
+
 def test_duplicate_registration_rejected():
     with pytest.raises(KeyError):
         @registry.register_agent("image_text_certify")

@@ -88,6 +88,46 @@ def test_certify_many_ranks_equal_consecutive_single_process_certify(world):
         assert out == expect and cursor == 3 * 128, (rank, out, expect)
 
 
+def _images_worker(rank, world, port, q, engine_name):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = {"images": ImagesEngine, "pair": PairEngine, "plain": IndexedEngine}[engine_name]()
+        s = cg.Smooth(eng, K, 0.5, seed=11)
+        xs = torch.zeros(5, 3, 8, 8)
+        q.put((rank, s.certify_images(xs, 51, 77, 0.01, 16), s._next_sample, eng.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,engine_name", [(2, "images"), (3, "images"), (2, "pair"), (3, "plain")])
+def test_image_sharded_certify_equals_consecutive_single_process_certify(world, engine_name):
+    """SURVEY.md 8(e), the zero-communication partition: every rank certifies WHOLE images (all 51 + 77 draws of each, at the
+    sample indices consecutive certify calls use); the only collective carries (label, radius) pairs.  5 images on 2 / 3 ranks:
+    ragged image shards, one rank of 3 with a single image (the pair path instead of the several-images protocol)."""
+    ref = cg.Smooth(IndexedEngine(), K, 0.5, seed=11)
+    xs = torch.zeros(5, 3, 8, 8)
+    expect = [ref.certify(xs[i], 51, 77, 0.01, 16) for i in range(5)]
+    one = cg.Smooth(ImagesEngine(), K, 0.5, seed=11)
+    assert one.certify_images(xs, 51, 77, 0.01, 16) == expect and one._next_sample == 5 * 128
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_images_worker, args=(r, world, port, q, engine_name)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    drawn = []
+    for rank, out, cursor, calls in got:
+        assert out == expect and cursor == 5 * 128, (rank, out, expect)
+        drawn += [(f, n) for f, n, _ in calls]
+    # every draw of every image was made exactly once, by one rank, as full 51- and 77-draw ranges (no sample sharding)
+    assert sorted(drawn) == sorted([(i * 128, 51) for i in range(5)] + [(i * 128 + 51, 77) for i in range(5)])
+
+
 def _single():
     s = cg.Smooth(IndexedEngine(), K, 0.5, seed=11)
     x = torch.zeros(3, 8, 8)

@@ -32,6 +32,10 @@ def _run(rank, world, port, q):
         out = (s.certify(x0, 25, 39, 0.05, 32), s.predict(x0, 30, 0.05, 7), s._sample_noise(x0, 11, 4).tolist(),
                s.certify_many(xs, 9, 11, 0.05, 32),                       # several images per fused pass, sharded
                [s.certify(xs[i], 9, 11, 0.05, 32) for i in range(3)])
+        cursor = s._next_sample                                            # image-sharded: rank 0 takes two images, rank 1 one
+        by_image = s.certify_images(xs, 9, 11, 0.05, 32)
+        s.reset(cursor)
+        out += (by_image, [s.certify(xs[i], 9, 11, 0.05, 32) for i in range(3)])
         q.put((rank, out))
         clf.close()
     finally:
@@ -66,6 +70,8 @@ def test_two_ranks_on_one_gpu_match_single_process():
     # certify_many consumes the same sample indices as consecutive certify calls would: re-run from the same cursor
     import certifiedgpt_amd as cg  # noqa: F401
     assert len(single[3]) == 3 and all(isinstance(r[0], int) for r in single[3])
+    # Smooth.certify_images (whole images per rank, no vote all-reduce) returns the list of the one-by-one loop from the same cursor
+    assert single[5] == single[6] and two[0][1][5] == two[0][1][6] == single[5]
 
 
 def _nccl_run(rank, world, port, q):
@@ -121,7 +127,7 @@ def test_bench_self_launches_its_ranks():
     root = os.path.dirname(HERE)
     env = dict(os.environ, CGPT_BENCH_ONE_GPU_REHEARSAL="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -134,6 +140,9 @@ def test_bench_self_launches_its_ranks():
         assert r["classifier_passes"] > 0 and r["all_reduce_device"] >= 0 and r["sample_noise_calls"] >= 1
         assert r["total"] >= r["classifier_passes"] * 0.5
     assert rk["rank_total_ms_max"] >= rk["rank_total_ms_min"] > 0
+    # both partitions of SURVEY.md 8(e) in one line: the image-sharded pass certifies the same images to the same (label, radius) list
+    im = line["image_sharded"]
+    assert im["equals_sample_sharded"] is True and im["value"] > 0 and im["images_per_rank_max"] == 2
     if torch.cuda.device_count() < 8:
         env.pop("CGPT_BENCH_ONE_GPU_REHEARSAL")
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],

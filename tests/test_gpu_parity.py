@@ -235,6 +235,27 @@ def test_vitg_n1000_sharded_125_per_gpu_equals_one_pass_and_oracle_statistics():
         clf.close()
 
 
+def test_vitg_image_sharded_certify_equals_sample_sharded_and_one_by_one(vitg):
+    """SURVEY.md 8(e) names two partitions of the path: samples over ranks (`certify` / `certify_many` + the vote all-reduce) and
+    whole images over ranks (`certify_images`, no vote collective).  At ViT-G size on one rank the three routes -- the one-by-one
+    loop of the reference (smoothing.py:29-56 per image), the fused several-images pass, the image-sharded pass -- return the same
+    (label, radius) list from the same cursor; and the image shards an 8-rank job would run (one image each, full 20 + 30 draws)
+    reproduce their rows of it."""
+    clf, cfg = vitg
+    xs = torch.stack([torch.from_numpy(mo.synthetic_image(cfg, seed=1234 + i)).to(DEV) for i in range(4)])
+    n0, n, alpha = 20, 30, 0.05
+    s = cg.Smooth(clf, 1000, 0.5, seed=42)
+    loop = [s.certify(xs[i], n0, n, alpha, 100) for i in range(4)]
+    s.reset()
+    many = s.certify_many(xs, n0, n, alpha, 100)
+    s.reset()
+    by_image = s.certify_images(xs, n0, n, alpha, 100)
+    assert loop == many == by_image and s._next_sample == 4 * (n0 + n)
+    for i in (3, 1):                                                      # a rank's shard: image i alone, at image i's cursor
+        s.reset(i * (n0 + n))
+        assert s.certify_images(xs[i:i + 1], n0, n, alpha, 100) == [loop[i]]
+
+
 def test_vitg_matches_oracle_on_two_samples(vitg):
     """Full-size numerical check: 2 noisy samples through ViT-G on the GPU vs the fp32 CPU oracle with the device's weights."""
     clf, cfg = vitg
