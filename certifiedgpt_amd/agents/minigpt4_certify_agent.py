@@ -8,8 +8,8 @@ Config (a plain dict or any mapping; the reference's YAMLs define no smoothing k
     run:   {agent: image_text_certify, output_dir: ..., seed: 0,
             smoothing: {sigma: 0.5, n0: 100, n: 100, alpha: 0.001, batch_size: 100, num_classes: 1000, radii: [0.25, 0.5, 1.0],
                         images_per_pass: 1,       # > 1: Smooth.certify_many (multi-GPU throughput mode)
-                        shard: samples}}          # images: Smooth.certify_images -- every rank certifies whole images (all their
-            #                                       draws) of each group of images_per_pass x world; no vote all-reduce
+                        shard: samples}}          # images: Smooth.certify_images / predict_images -- every rank takes whole images
+            #                                       (all their draws) of each group of images_per_pass x world; no vote all-reduce
     model: {generate: {llama_model: <LOCAL dir>, prompt | question: ..., answers: [...], max_new_tokens: 20},   # optional: full
             #          MiniGPT-4 `generate` as the base classifier (certifiedgpt_amd/minigpt4.py); classes = the answer vocabulary
             mode: vit_head | encode_img, weights: <path to a torch state_dict saved with torch.save> | null, dims: {...},
@@ -71,8 +71,8 @@ class CertifyLoop:
 
         # images_per_pass > 1 (certify only): Smooth.certify_many runs the per-rank sample slices of several images in one
         # classifier batch and one all-reduce -- the multi-GPU throughput mode; results equal the one-by-one loop.
-        group = int(sm_cfg.get("images_per_pass", 1)) if mode == "certify" else 1
-        by_image = mode == "certify" and sm_cfg.get("shard", "samples") == "images"
+        by_image = sm_cfg.get("shard", "samples") == "images"
+        group = int(sm_cfg.get("images_per_pass", 1)) if (mode == "certify" or by_image) else 1
         if sm_cfg.get("shard", "samples") not in ("samples", "images"):
             raise ValueError(f"run.smoothing.shard must be 'samples' or 'images', not {sm_cfg.get('shard')!r}")
         if by_image:                                       # SURVEY.md 8(e), the zero-communication mode: whole images per rank
@@ -84,8 +84,12 @@ class CertifyLoop:
             if not pending:
                 return
             t0 = time.perf_counter()
-            many = smooth.certify_images if by_image else smooth.certify_many
-            outs = many(torch.stack([p[1] for p in pending]), sm_cfg["n0"], sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"])
+            xs = torch.stack([p[1] for p in pending])
+            if mode != "certify":                          # predict agent, image-sharded
+                outs = [(lab, 0.0) for lab in smooth.predict_images(xs, sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"])]
+            else:
+                many = smooth.certify_images if by_image else smooth.certify_many
+                outs = many(xs, sm_cfg["n0"], sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"])
             dt = (time.perf_counter() - t0) / len(pending)
             for (idx, _, label), (pred, radius) in zip(pending, outs):
                 emit(idx, label, pred, radius, dt)

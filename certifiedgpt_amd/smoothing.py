@@ -204,6 +204,26 @@ class Smooth(object):
         t = table.cpu().numpy()
         return [(int(t[i, 0]), float(t[i, 1])) for i in range(G)]
 
+    def predict_images(self, xs, n: int, alpha: float, batch_size: int):
+        """`predict` (smoothing.py:58-79) for a stack of images, image-sharded like `certify_images`: rank r takes whole images,
+        image i draws the n indices the i-th of G consecutive `predict` calls would use; the labels (ABSTAIN = -1 included) are
+        exchanged at 8 bytes per image.  Returns a list of numpy.int64 / ABSTAIN exactly as G `predict` calls return them."""
+        G = int(xs.shape[0])
+        first = self._next_sample
+        self._next_sample += G * n
+        rank, world = _world(self.process_group)
+        lo, hi = shard_range(G, rank, world)
+        table = torch.zeros(G, dtype=torch.float64, device=xs.device)
+        if hi > lo:
+            with torch.no_grad():
+                c = self._timed_compute(lambda: self._counts_of_images(xs[lo:hi], first + lo * n, n, 0, batch_size))
+            c = c.cpu().numpy().astype(int)
+            table[lo:hi] = torch.tensor([float(self.predict_from_counts(c[i, 0], alpha)) for i in range(hi - lo)],
+                                        dtype=torch.float64).to(table.device)
+        if world > 1:
+            self._all_reduce(table)
+        return [self._predicted(int(v)) for v in table.cpu().numpy()]
+
     def _counts_of_images(self, xs, first: int, n0: int, n: int, batch_size) -> torch.Tensor:
         """int64 [g, 2, K]: selection and estimation histograms of g images, every draw on THIS rank; image i uses the indices
         first + i (n0 + n) ... (the cursor positions of consecutive `certify` calls)."""

@@ -83,6 +83,17 @@ def test_image_sharded_mode_gives_the_same_records_and_bad_mode_is_refused(tmp_p
         agent.run()
         outs.append([(r["idx"], r["label"], r["predict"], r["radius"]) for r in agent.records])
     assert outs[0] == outs[1] and len(outs[0]) == 3
+    preds = []
+    for shard in ("samples", "images"):                      # the predict agent: Smooth.predict one by one | Smooth.predict_images
+        cfg = _config(tmp_path / ("p" + shard), "image_text_predict")
+        cfg["run"]["smoothing"].update(images_per_pass=2, shard=shard)
+        registry.register("configuration", cfg)
+        agent = setup_agent(cfg)
+        agent.classifier = Engine()
+        agent.dataset = [(torch.zeros(3, 8, 8), 2), (torch.zeros(3, 8, 8), 1), (torch.zeros(3, 8, 8), 2)]
+        agent.run()
+        preds.append([(r["idx"], r["label"], r["predict"]) for r in agent.records])
+    assert preds[0] == preds[1] and [p[2] for p in preds[0]] == [2, 2, 2]
     cfg = _config(tmp_path / "bad", "image_text_certify")
     cfg["run"]["smoothing"]["shard"] = "pixels"
     registry.register("configuration", cfg)

@@ -95,7 +95,9 @@ def _images_worker(rank, world, port, q, engine_name):
         eng = {"images": ImagesEngine, "pair": PairEngine, "plain": IndexedEngine}[engine_name]()
         s = cg.Smooth(eng, K, 0.5, seed=11)
         xs = torch.zeros(5, 3, 8, 8)
-        q.put((rank, s.certify_images(xs, 51, 77, 0.01, 16), s._next_sample, eng.calls))
+        out = s.certify_images(xs, 51, 77, 0.01, 16)
+        calls = list(eng.calls)
+        q.put((rank, out, s._next_sample, calls, s.predict_images(xs, 125, 0.001, 32)))
     finally:
         dist.destroy_process_group()
 
@@ -108,8 +110,11 @@ def test_image_sharded_certify_equals_consecutive_single_process_certify(world, 
     ref = cg.Smooth(IndexedEngine(), K, 0.5, seed=11)
     xs = torch.zeros(5, 3, 8, 8)
     expect = [ref.certify(xs[i], 51, 77, 0.01, 16) for i in range(5)]
+    expect_pred = [ref.predict(xs[i], 125, 0.001, 32) for i in range(5)]          # continues at the cursor certify left
     one = cg.Smooth(ImagesEngine(), K, 0.5, seed=11)
     assert one.certify_images(xs, 51, 77, 0.01, 16) == expect and one._next_sample == 5 * 128
+    got_pred = one.predict_images(xs, 125, 0.001, 32)
+    assert got_pred == expect_pred and [type(v) for v in got_pred] == [type(v) for v in expect_pred]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -121,8 +126,9 @@ def test_image_sharded_certify_equals_consecutive_single_process_certify(world, 
         p.join(timeout=60)
         assert p.exitcode == 0
     drawn = []
-    for rank, out, cursor, calls in got:
+    for rank, out, cursor, calls, pred in got:
         assert out == expect and cursor == 5 * 128, (rank, out, expect)
+        assert pred == expect_pred and [type(v) for v in pred] == [type(v) for v in expect_pred]
         drawn += [(f, n) for f, n, _ in calls]
     # every draw of every image was made exactly once, by one rank, as full 51- and 77-draw ranges (no sample sharding)
     assert sorted(drawn) == sorted([(i * 128, 51) for i in range(5)] + [(i * 128 + 51, 77) for i in range(5)])

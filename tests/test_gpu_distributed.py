@@ -36,6 +36,10 @@ def _run(rank, world, port, q):
         by_image = s.certify_images(xs, 9, 11, 0.05, 32)
         s.reset(cursor)
         out += (by_image, [s.certify(xs[i], 9, 11, 0.05, 32) for i in range(3)])
+        cursor = s._next_sample
+        pred_by_image = [int(v) for v in s.predict_images(xs, 30, 0.05, 7)]
+        s.reset(cursor)
+        out += (pred_by_image, [int(s.predict(xs[i], 30, 0.05, 7)) for i in range(3)])
         q.put((rank, out))
         clf.close()
     finally:
@@ -72,6 +76,7 @@ def test_two_ranks_on_one_gpu_match_single_process():
     assert len(single[3]) == 3 and all(isinstance(r[0], int) for r in single[3])
     # Smooth.certify_images (whole images per rank, no vote all-reduce) returns the list of the one-by-one loop from the same cursor
     assert single[5] == single[6] and two[0][1][5] == two[0][1][6] == single[5]
+    assert single[7] == single[8] and two[0][1][7] == two[0][1][8] == single[7]
 
 
 def _nccl_run(rank, world, port, q):

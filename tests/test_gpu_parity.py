@@ -254,6 +254,11 @@ def test_vitg_image_sharded_certify_equals_sample_sharded_and_one_by_one(vitg):
     for i in (3, 1):                                                      # a rank's shard: image i alone, at image i's cursor
         s.reset(i * (n0 + n))
         assert s.certify_images(xs[i:i + 1], n0, n, alpha, 100) == [loop[i]]
+    s.reset(1000)
+    one_by_one = [s.predict(xs[i], 40, alpha, 100) for i in range(4)]     # smoothing.py:58-79 per image
+    s.reset(1000)
+    together = s.predict_images(xs, 40, alpha, 100)
+    assert together == one_by_one and [type(v) for v in together] == [type(v) for v in one_by_one]
 
 
 def test_vitg_matches_oracle_on_two_samples(vitg):
