@@ -175,6 +175,24 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 #define CGPT9_PH_BEGIN
 #define CGPT9_PH(k)
 #endif
+// The 8 x JN MFMAs of one half of an M segment: rows R0 + 0..3 of the wave tile against JN column tiles (fragments BF), both k-steps.  An
+// accumulator sees k-step 0 before k-step 1 in either order (the K order per element is what bit-identity rests on).
+//   CGPT_MFMA_ORDER 0: row-tile-major -- neighbours share the A fragment in pairs, every other transition shares nothing.
+//   CGPT_MFMA_ORDER 1: column-tile-major with the rows walked back and forth -- every transition inside a k-step keeps one of the two
+//                      fragment operands (a bare MFMA loop sustains 3 % more with one operand kept than with none: profiles/r04/mfma_sustained.txt).
+#ifndef CGPT_MFMA_ORDER
+#define CGPT_MFMA_ORDER 0
+#endif
+#if CGPT_MFMA_ORDER == 0
+#define CGPT9_MM(R0, BF, JN, C0)                                                                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < JN; ++j)   \
+        acc[R0 + i][C0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[R0 + i][C0 + j], 0, 0, 0);
+#else
+#define CGPT9_MM(R0, BF, JN, C0)                                                                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < JN; ++j) _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) { \
+        const int i = (j & 1) ? 3 - ii : ii;                                                                                             \
+        acc[R0 + i][C0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[R0 + i][C0 + j], 0, 0, 0); }
+#endif
     auto tile_body = [&](auto tnv_tag, int tm, int ncol0) __attribute__((always_inline)) {
         constexpr int TNv = decltype(tnv_tag)::value;                       // column tiles of 16 per wave: 4, or 3 (192-column tile)
         constexpr bool NARROW = TNv == 3;
@@ -228,20 +246,8 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             CGPT9_PH(0)
             CGPT_SLOT_END
             CGPT9_PH(1)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < N1; ++j)
-                        acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[i][2 + j], 0, 0, 0);
+            CGPT9_MM(0, bf0, 2, 0)
+            CGPT9_MM(0, bf1, N1, 2)
             CGPT9_PH(2)
             CGPT_SLOT_END
             CGPT9_PH(3)
@@ -262,20 +268,8 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
             CGPT9_PH(4)
             CGPT_SLOT_END
             CGPT9_PH(5)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < N1; ++j)
-                        acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[4 + i][2 + j], 0, 0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[j][ks], af[i][ks], (Z && ks == 0) ? zero4 : acc[4 + i][j], 0, 0, 0);
+            CGPT9_MM(4, bf1, N1, 2)
+            CGPT9_MM(4, bf0, 2, 0)
             CGPT9_PH(6)
             CGPT_SLOT_END
             CGPT9_PH(7)

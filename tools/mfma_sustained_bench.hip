@@ -12,7 +12,9 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool LDS, bool DMA = false>
+// ORDER (MFMA-only variants): 0 = the A operand stays for four consecutive MFMAs (i outer, j inner: the GEMM's order shares one operand
+// between neighbours too), 1 = no operand shared between consecutive MFMAs (diagonal walk), 2 = both operands the same registers throughout.
+template <bool LDS, bool DMA = false, int ORDER = 0>
 __global__ __launch_bounds__(512) void mfma_loop(const f16x8* __restrict__ src, float* out, unsigned long long* clk, int iters) {
     __shared__ __attribute__((aligned(16))) f16x8 lds[DMA ? 8192 : 4096];    // 64 KiB of operand-shaped data (+ 64 KiB that the LDS-DMA requests fill)
     const int tid = threadIdx.x;
@@ -29,7 +31,11 @@ __global__ __launch_bounds__(512) void mfma_loop(const f16x8* __restrict__ src, 
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    if (ORDER == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    else if (ORDER == 1) acc[j][(i + j) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[(i + j) & 3], acc[j][(i + j) & 3], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc[i][j], 0, 0, 0);
+                }
             if (LDS) {                                                       // 6 fragment reads per 16 MFMAs (24 per 64)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[i] = lds[(rd + i * 64) & 4095];
@@ -54,13 +60,13 @@ __global__ __launch_bounds__(512) void mfma_loop(const f16x8* __restrict__ src, 
     if (tid == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-template <bool LDS, bool DMA = false> void run(const char* name, int threads, const f16x8* src) {
+template <bool LDS, bool DMA = false, int ORDER = 0> void run(const char* name, int threads, const f16x8* src) {
     float* out; unsigned long long* clk;
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&clk, 256 * 2 * 8);
     const int iters = 20000;                                                 // 320 000 MFMAs per wave
     const double flop = 256.0 * (threads / 64) * iters * 16.0 * (2.0 * 16 * 16 * 32);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto launch = [&] { hipLaunchKernelGGL((mfma_loop<LDS, DMA>), dim3(256), dim3(threads), 0, 0, src, out, clk, iters); };
+    auto launch = [&] { hipLaunchKernelGGL((mfma_loop<LDS, DMA, ORDER>), dim3(256), dim3(threads), 0, 0, src, out, clk, iters); };
     launch(); hipDeviceSynchronize();
     hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
     float one; hipEventElapsedTime(&one, e0, e1);
@@ -94,6 +100,9 @@ int main() {
         run<true>("MFMA + the GEMM's LDS fragment reads, random", th, dr);
         run<true, true>("... + its LDS-DMA requests (8 KiB / 64 MFMAs)", th, dr);
         run<false>("MFMA only, zero operands", th, dz);
+        run<false, false, 1>("MFMA only, random, no operand shared by neighbours", th, dr);
+        run<false, false, 2>("MFMA only, random, same two operands throughout", th, dr);
+        run<false>("MFMA only, random operands (again)", th, dr);
     }
     return 0;
 }
