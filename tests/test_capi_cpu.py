@@ -45,6 +45,32 @@ def test_no_gpu_fails_loudly():
     assert e.value.code == 2  # CGPT_ERR_NO_DEVICE
 
 
+def test_missing_library_fails_loudly_and_product_never_touches_the_oracle():
+    """The product path has no fallback: with the HIP extension absent, the first use raises ImportError naming the build step
+    (nothing is computed some other way).  And importing / using the product pulls in nothing from oracle/: the oracle is test
+    infrastructure (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg only)."""
+    import subprocess
+    import sys
+    code = ("import sys, certifiedgpt_amd as cg\n"
+            "try:\n    cg.Smooth(object(), 3, 0.5)\n    print('NO ERROR')\n"
+            "except ImportError as e:\n    print('ImportError', 'no CPU fallback' in str(e))\n")
+    env = dict(os.environ, CGPT_LIB_PATH=os.path.join(ROOT, "does", "not", "exist", "libcgpt.so"), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.stdout.strip() == "ImportError True", (r.stdout, r.stderr[-500:])
+    code = ("import sys, numpy as np, certifiedgpt_amd as cg\n"
+            "import certifiedgpt_amd.agents, certifiedgpt_amd.minigpt4, certifiedgpt_amd.rgf\n"
+            "s = cg.Smooth(object(), 3, 0.5)\n"
+            "s.certify_from_counts(np.array([9, 1, 0]), np.array([90, 10, 0]), 100, 0.001)\n"
+            "print(sorted(m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')))\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "[]", (r.stdout, r.stderr[-500:])
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|import_module\(\s*['\"]oracle", re.M)
+    for d, _, files in os.walk(os.path.join(ROOT, "certifiedgpt_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert not pat.search(open(os.path.join(d, f)).read()), f"{os.path.join(d, f)} imports the oracle"
+
+
 def _smooth(sigma=0.5, K=3):
     class _Eval:
         def eval(self):
