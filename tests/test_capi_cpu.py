@@ -230,3 +230,54 @@ print('ok')
     if len(libs) < 2:                                         # visible in the report instead of a silent pass of half the test
         pytest.skip(f"only {len(libs)} librccl file(s) on this machine ({libs}): the none-mapped refusal ran, the two-instance refusal did not")
     assert "two-instances-refused" in r.stdout, r.stdout
+
+
+def test_statistics_properties_hold_over_random_counts():
+    """Size-independent properties of the float64 statistics behind certify / predict (smoothing.py:46-56,73-79,107-117), checked
+    with hypothesis over N up to 100 000: the Clopper-Pearson bound is a probability, below NA / N, increasing in NA and in alpha;
+    R = sigma * Phi^-1(bound) exactly as certify computes it, abstaining precisely when the bound is below 1/2; relabelling the
+    classes relabels the answer (no dependence on class ids beyond the first-index tie rule); the binomial test is symmetric."""
+    from hypothesis import given, settings, strategies as st
+    L = cg.lib()
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(1, 100000), st.data())
+    def bound(n, data):
+        na = data.draw(st.integers(0, n))
+        alpha = data.draw(st.sampled_from([1e-4, 1e-3, 0.01, 0.05]))
+        b = L.cgpt_lower_confidence_bound(na, n, alpha)
+        assert 0.0 <= b <= 1.0 and b <= na / n + 1e-15
+        if na < n:
+            assert L.cgpt_lower_confidence_bound(na + 1, n, alpha) >= b
+        assert L.cgpt_lower_confidence_bound(na, n, min(0.5, alpha * 2)) >= b - 1e-15
+        if na == 0:
+            assert b == 0.0                                   # smoothing.py:117 via proportion_confint: 0 successes -> 0
+        k = data.draw(st.integers(0, n))
+        assert abs(L.cgpt_binom_test(k, n, 0.5) - L.cgpt_binom_test(n - k, n, 0.5)) <= 1e-12
+    bound()
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(0, 400), min_size=2, max_size=12), st.sampled_from([0.25, 0.5, 1.0]), st.sampled_from([1e-3, 0.05]), st.randoms())
+    def decisions(counts, sigma, alpha, rnd):
+        n = sum(counts)
+        if n == 0:
+            return
+        s = _smooth(sigma, len(counts))
+        lab, rad = s.certify_from_counts(counts, counts, n, alpha)
+        top = int(np.argmax(counts))
+        b = L.cgpt_lower_confidence_bound(counts[top], n, alpha)
+        if b < 0.5:
+            assert (lab, rad) == (cg.Smooth.ABSTAIN, 0.0)
+        else:
+            assert lab == top and rad == sigma * L.cgpt_norm_ppf(b)
+        perm = list(range(len(counts)))
+        rnd.shuffle(perm)
+        pc = [counts[perm[i]] for i in range(len(counts))]
+        if sorted(counts)[-1] != sorted(counts)[-2]:          # a unique winner: the answer moves with its class
+            plab, prad = s.certify_from_counts(pc, pc, n, alpha)
+            assert prad == rad and (plab == cg.Smooth.ABSTAIN) == (lab == cg.Smooth.ABSTAIN)
+            if lab != cg.Smooth.ABSTAIN:
+                assert perm[plab] == lab
+            p1, p2 = s.predict_from_counts(counts, alpha), s.predict_from_counts(pc, alpha)
+            assert (p1 == cg.Smooth.ABSTAIN) == (p2 == cg.Smooth.ABSTAIN) and (p1 == cg.Smooth.ABSTAIN or perm[p2] == p1)
+    decisions()
