@@ -180,9 +180,6 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
 //   CGPT_MFMA_ORDER 0: row-tile-major -- neighbours share the A fragment in pairs, every other transition shares nothing.
 //   CGPT_MFMA_ORDER 1: column-tile-major with the rows walked back and forth -- every transition inside a k-step keeps one of the two
 //                      fragment operands (a bare MFMA loop sustains 3 % more with one operand kept than with none: profiles/r04/mfma_sustained.txt).
-#ifndef CGPT_EPI_PERMLANE
-#define CGPT_EPI_PERMLANE 0
-#endif
 #ifndef CGPT_MFMA_ORDER
 #define CGPT_MFMA_ORDER 0
 #endif
@@ -304,50 +301,6 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // before the first pass overwrites the scratch
         const bool full = (tm + 1) * BM2 <= p.M && ncol0 + (NARROW ? 192 : BN_) <= p.N;
         constexpr bool F16_OUT = EPI == EPI_F16 || EPI == EPI_F16_GELU;
-#if CGPT_EPI_PERMLANE
-        if (F16_OUT && full && (p.ldo & 7) == 0 && !(p.ablate & 512)) {
-            // Experiment (profiles/r04/gemm_permlane_epilogue.txt): fp16 output of a full tile WITHOUT the LDS transposition.  A lane owns
-            // 4 columns (two packed dwords) of row e15 in every 16 x 16 accumulator tile; v_permlane16_swap between the dwords of two
-            // tiles X, Y leaves lane groups 0 / 2 with columns 0-7 / 8-15 of X and groups 1 / 3 with those of Y: 16 contiguous bytes
-            // per lane, one global_store_dwordx4 per pair of tiles (adjacent column tiles: 64 contiguous bytes per row and instruction).
-            half_t* outp = reinterpret_cast<half_t*>(p.out);
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            auto pack = [&](const f32x4& v, unsigned& d0, unsigned& d1) __attribute__((always_inline)) {
-                f16x4 hv;
-                if constexpr (GELU) hv = gelu_f16x4(v);
-                else hv = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 d = __builtin_bit_cast(u32x2, hv);
-                d0 = d[0]; d1 = d[1];
-            };
-            auto store_pair = [&](const f32x4& vx, const f32x4& vy, half_t* dst) __attribute__((always_inline)) {
-                unsigned x0, x1, y0, y1;
-                pack(vx, x0, x1);
-                pack(vy, y0, y1);
-                const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-                const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-                const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                CGPT9_STORE16(o, reinterpret_cast<u32x4*>(dst));
-            };
-            const int colq = ((eg & 1) ? 16 : 0) + ((eg & 2) ? 8 : 0);     // adjacent column tiles X | Y
-            half_t* const base = outp + ((int64_t)tm * BM2 + wr * 128 + e15) * p.ldo + ncol0 + wc * wcols;
-            if (late) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i == 4) { if (late) __builtin_amdgcn_s_setprio(0); }
-                half_t* const rowp = base + (int64_t)(i * 16) * p.ldo;
-#pragma unroll
-                for (int jp = 0; jp < TNv / 2; ++jp)
-                    store_pair(acc[i][2 * jp] + bias4[2 * jp], acc[i][2 * jp + 1] + bias4[2 * jp + 1], rowp + jp * 32 + colq);
-                if constexpr (NARROW) {
-                    // the third column tile of row tiles i, i + 1 pairs up: groups 0 / 2 store row tile i, groups 1 / 3 row tile i + 1
-                    if ((i & 1) == 1)
-                        store_pair(acc[i - 1][2] + bias4[2], acc[i][2] + bias4[2],
-                                   base + (int64_t)((i - 1 + (eg & 1)) * 16) * p.ldo + 32 + ((eg & 2) ? 8 : 0));
-                }
-            }
-        } else
-#endif
         if (F16_OUT && full && (p.ldo & 7) == 0 && !(p.ablate & 512)) {
             // fp16 output of a full tile, transposed through the wave's 4-KiB scratch: four passes of 32 rows x 64 columns; rows are
             // 128 B with the 16-byte chunk index XOR-swizzled by row & 7; a lane then stores 16 contiguous bytes, 8 lanes one line
