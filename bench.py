@@ -348,11 +348,14 @@ def main():
         traffic_note = "no usable PMC summary under profiles/ (%r)" % (e,)
 
     fc1_ms, fc1_flops, fc1_n = clf.profile_read(1)
+    fc1_clock = clf.profile_clock(1)                  # in-kernel: sum of the workgroups' shader cycles / 100-MHz ticks, timed region only
     by_kind = {}
     for kind, name in ((2, "qkv"), (3, "proj"), (1, "fc1_gelu"), (4, "fc2")):
         ms, fl, cnt = clf.profile_read(kind)
         if cnt:
-            by_kind[name] = {"avg_launch_us": 1e3 * ms / cnt, "tflops": fl / (ms * 1e-3) / 1e12, "launches": cnt}
+            by_kind[name] = {"avg_launch_us": 1e3 * ms / cnt, "tflops": fl / (ms * 1e-3) / 1e12, "launches": cnt,
+                             "in_kernel_clock_ghz": clf.profile_clock(kind)}
+    all_clock = clf.profile_clock(0)
     all_ms, all_flops, all_n = clf.profile_read(0)
 
     # The reference-shaped call, outside the timed region: ONE Smooth.certify(x, n0, n, alpha, batch_size = n0 + n) per image
@@ -486,10 +489,14 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm9_f16_kernel<1> = <EPI_F16_GELU> (ViT MLP fc1 + GELU, M=batch*257, N=6144, K=1408)",
                          "achieved": fc1_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": fc1_tflops / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "in_kernel_clock_ghz": fc1_clock,
+                         "in_kernel_clock_note": "shader clock this kernel held in THIS run: d(s_memtime) / d(s_memrealtime) x 100 MHz summed over all "
+                                                 "workgroups of its launches in the timed region (the data sheet's peak assumes 2.4 GHz): frac = "
+                                                 "MFMA-busy fraction x this / 2.4",
                          "launches": fc1_n, "avg_launch_ms": fc1_ms / max(fc1_n, 1),
                          "flop_per_launch": fc1_flops / max(fc1_n, 1),
                          "all_gemms": {"achieved": all_tflops, "frac": all_tflops / MFMA_PEAK_TFLOPS, "launches": all_n,
-                                       "total_ms": all_ms},
+                                       "total_ms": all_ms, "in_kernel_clock_ghz": all_clock},
                          "vit_gemms": by_kind,
                          "pmc": pmc_fc1, "device_sustained": sustained},
             "results_sample": [[int(l), float(r)] for l, r in results[-3:]],

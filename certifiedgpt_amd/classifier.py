@@ -203,6 +203,13 @@ class HipClassifier:
         _lib.check(self._L.cgpt_profile_read(self._h, kind, C.byref(ms), C.byref(fl), C.byref(n)))
         return ms.value, fl.value, n.value
 
+    def profile_clock(self, kind=0):
+        """GHz the profiled GEMMs of `kind` ran at (in-kernel s_memtime / s_memrealtime of every workgroup; cgpt_profile_clock).
+        Read before profile_read(0), which resets the sums.  0.0 when nothing was profiled."""
+        ghz = C.c_double()
+        _lib.check(self._L.cgpt_profile_clock(self._h, kind, C.byref(ghz)))
+        return ghz.value
+
 
 def interpolate_pos_embed(pos_embed, num_patches):
     """Resize a checkpoint's position embedding [1, 1+P0, D] to this model's grid (reference interpolate_pos_embed,

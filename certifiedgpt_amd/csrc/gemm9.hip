@@ -60,6 +60,8 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) half_t smem9[];
     half_t* const scratch_all = smem9 + 2 * STAGE;
 
+    // in-kernel clock (cgpt_profile_clock): two scalar counter reads here and at the end, d(s_memtime) / d(s_memrealtime) x 100 MHz
+    const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -377,6 +379,10 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         for (int k = 0; k < 8; ++k) e[k] = ph9[k];
     }
 #endif
+    if (p.clk && threadIdx.x == 0) {
+        atomicAdd(p.clk, __builtin_amdgcn_s_memtime() - clk_c0);
+        atomicAdd(p.clk + 1, __builtin_amdgcn_s_memrealtime() - clk_r0);
+    }
 #undef CGPT_FENCE
 #undef CGPT_SLOT_END
 }

@@ -27,6 +27,8 @@ struct GemmParams {
     int M, N, K;
     int patches;                  // EPI_PATCH: P (patches per image)
     unsigned long long* dbg = nullptr;   // diagnostic builds only (-DCGPT_STAMPS): per-wave cycle sums
+    unsigned long long* clk = nullptr;   // measurement hook (cgpt_profile_clock), 256-row kernels: += every workgroup's shader cycles [0] and
+                                         // 100-MHz ticks [1] from its first to its last instruction; null = off
     int group_m = 8;              // tile-rows per group in the block->tile map (speed only)
     int ablate = 0;               // lab builds: 1 = no in-loop loads, 2 = no epilogue stores, 4 = no MFMAs; tests: see launch_gemm
 };

@@ -91,6 +91,7 @@ struct cgpt_model {
     bool pending_delta = false;   // CGPT_MODE_VIT_HEAD: the last block's fc2 output has been added to the CLS rows only
     bool profile = false;
     std::vector<ProfEvent> events;
+    unsigned long long* clk_dev = nullptr;   // [8][2]: per GEMM kind, shader cycles and 100-MHz ticks summed over workgroups (cgpt_profile_clock)
 };
 
 namespace {
@@ -299,6 +300,7 @@ cgpt_status gemm(cgpt_model* m, int epi, const half_t* A, int64_t lda, const hal
     if (m->profile) {
         HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
         HIPCHK(hipEventRecord(ev.a, st));
+        if (m->clk_dev && kind >= 0 && kind < 8) p.clk = m->clk_dev + 2 * kind;
     }
     HIPCHK(launch_gemm(epi, p, st));
     if (m->profile) {
@@ -449,6 +451,7 @@ cgpt_status cgpt_create(const cgpt_config* cfg, cgpt_handle* out) {
     cgpt_model* m = new cgpt_model();
     m->cfg = c;
     cgpt_status s = build(m);
+    if (s == CGPT_OK) s = dev_alloc(m, 16 * sizeof(unsigned long long), (void**)&m->clk_dev);
     if (s != CGPT_OK) { cgpt_destroy(m); return s; }
     HIPCHK(hipDeviceSynchronize());
     *out = m;
@@ -807,6 +810,20 @@ cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on) {
     return CGPT_OK;
 }
 
+cgpt_status cgpt_profile_clock(cgpt_handle h, int32_t kind, double* clock_ghz) {
+    if (!h || !clock_ghz || kind < 0 || kind >= 8) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_profile_clock: null argument or kind outside 0..7");
+    *clock_ghz = 0.0;
+    if (!h->clk_dev) return CGPT_OK;
+    unsigned long long host[16];
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host, h->clk_dev, sizeof(host), hipMemcpyDeviceToHost));
+    double cyc = 0, ticks = 0;
+    for (int k = 0; k < 8; ++k)
+        if (kind == 0 || k == kind) { cyc += (double)host[2 * k]; ticks += (double)host[2 * k + 1]; }
+    if (ticks > 0) *clock_ghz = cyc / ticks * 0.1;          // s_memrealtime counts at 100 MHz
+    return CGPT_OK;
+}
+
 cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, double* total_flops, int64_t* launches) {
     if (!h || !total_ms || !total_flops || !launches) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_profile_read: null argument");
     double ms = 0, fl = 0; int64_t n = 0;
@@ -818,9 +835,10 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
             ms += t; fl += e.flops; ++n;
         }
     }
-    if (kind == 0) {   // reading "all" drains the log
+    if (kind == 0) {   // reading "all" drains the log (and the in-kernel clock sums: every event has been synchronised above)
         for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         h->events.clear();
+        if (h->clk_dev) HIPCHK(hipMemset(h->clk_dev, 0, 16 * sizeof(unsigned long long)));
     }
     *total_ms = ms; *total_flops = fl; *launches = n;
     return CGPT_OK;

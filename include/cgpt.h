@@ -214,6 +214,11 @@ double cgpt_norm_ppf(double p);
  * (GELU epilogue) GEMMs only, 2 = ViT qkv, 3 = ViT attention proj, 4 = ViT MLP fc2. */
 cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on);
 cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
+/* The shader clock the profiled GEMMs of `kind` (as above; 0 = all) actually ran at: every workgroup of the 256-row kernels reads
+ * s_memtime and s_memrealtime at its first and last instruction while profiling is on; clock_ghz = sum of cycles / sum of 100-MHz
+ * ticks x 0.1 (0 when nothing was profiled).  Synchronises the device.  Read it BEFORE cgpt_profile_read(kind 0), which resets
+ * the sums with the log.  roofline.frac = MFMA-busy fraction x this clock / 2.4 GHz, so a clock give-back shows up here. */
+cgpt_status cgpt_profile_clock(cgpt_handle h, int32_t kind, double* clock_ghz);
 
 /* Process-wide SPEED knobs.  No option changes a result: every accepted value gives bit-identical outputs (tested).
  *   "gemm_kernel": 0 = automatic choice (default); 1 = 128x128 register-staged tile, 3 = 256x128 direct-to-LDS tile,

@@ -235,6 +235,30 @@ def test_vitg_n1000_sharded_125_per_gpu_equals_one_pass_and_oracle_statistics():
         clf.close()
 
 
+def test_vitg_profile_reports_times_flops_and_the_in_kernel_clock(vitg):
+    """The measurement hooks behind bench.py's roofline: with profiling on, every GEMM launch is timed with HIP events on the launch
+    stream and the 256-row kernels report the shader clock they ran at (s_memtime / s_memrealtime per workgroup).  The counts are
+    unchanged by profiling; reading kind 0 drains the log and the clock sums."""
+    clf, cfg = vitg
+    x = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    plain = clf.sample_counts(x, 0, 100, 100, 0.5, 42)
+    clf.profile_read(0)
+    clf.profile(True)
+    try:
+        prof = clf.sample_counts(x, 0, 100, 100, 0.5, 42)
+        ms, fl, n = clf.profile_read(1)                                      # fc1 + GELU: one launch per block
+        assert n == 39 and abs(fl - 39 * 2.0 * 100 * 257 * 6144 * 1408) < 1e6 and 0 < ms < 1000
+        ghz = {k: clf.profile_clock(k) for k in (0, 1, 2, 3, 4)}
+        assert all(0.8 < v < 2.6 for v in ghz.values()), ghz              # MI355X: 2.4 GHz peak, lower under MFMA load
+        tflops = fl / (ms * 1e-3) / 1e12
+        assert tflops < 2500.0 * ghz[1] / 2.4 + 1e-9                         # no kernel beats 1 024 FLOP/clk/SIMD at the clock it ran at
+        clf.profile_read(0)
+        assert clf.profile_clock(0) == 0.0 and clf.profile_read(0)[2] == 0
+    finally:
+        clf.profile(False)
+    assert torch.equal(plain, prof)
+
+
 def test_vitg_image_sharded_certify_equals_sample_sharded_and_one_by_one(vitg):
     """SURVEY.md 8(e) names two partitions of the path: samples over ranks (`certify` / `certify_many` + the vote all-reduce) and
     whole images over ranks (`certify_images`, no vote collective).  At ViT-G size on one rank the three routes -- the one-by-one
