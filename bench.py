@@ -176,8 +176,18 @@ def main():
         sys.exit(2)
     import torch.distributed as dist
     backend = None
-    if world > 1:
+    # CGPT_BENCH_FORCE_NCCL=1 on ONE GPU: the whole multi-rank code path -- process group "nccl" (= RCCL), the all-reduce of the CUDA
+    # int64 vote histograms, dist.barrier(device_ids=...), the `ranks` report -- with a world of one rank, so that a one-GPU box
+    # executes on hardware what an 8-GPU run executes (a SUM over one rank changes nothing; the line says summed_ranks = 1).
+    forced = world == 1 and os.environ.get("CGPT_BENCH_FORCE_NCCL", "") not in ("", "0")
+    collective = world > 1 or forced
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         torch.cuda.set_device(local)
         backend = "gloo" if rehearsal else "nccl"            # "nccl" IS RCCL on ROCm
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -239,11 +249,12 @@ def main():
         vocab = sorted(set(probe.generate_from_embeds(emb, prompt)))[:NUM_CLASSES - 1]
         base = MiniGPT4Classifier(clf, llm, tok, prompt, AnswerLabelMap(NUM_CLASSES, vocab, frozen=True), max_new_tokens=20, max_batch=per_gpu,
                                   decode=args.decode, prefill_linear=args.prefill_linear)
-    smooth = cg.Smooth(base, NUM_CLASSES, SIGMA, seed=42, non_certifiable=(base.label_map.other_id,) if gen else ())
+    smooth = cg.Smooth(base, NUM_CLASSES, SIGMA, seed=42, non_certifiable=(base.label_map.other_id,) if gen else (),
+                       force_collective=forced)
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if collective:
             if backend == "nccl":
                 dist.barrier(device_ids=[local])      # this rank's own GPU, explicitly
             else:
@@ -269,7 +280,7 @@ def main():
     torch.cuda.synchronize()
     clf.profile_read(0)
     clf.profile(True)
-    if world > 1:
+    if collective:
         smooth.collect_timing(True)                  # HIP events around each rank's classifier pass and around the all-reduce
     barrier()
     torch.cuda.synchronize()
@@ -281,7 +292,7 @@ def main():
     elapsed = time.perf_counter() - t0
     clf.profile(False)
     ranks_report = None
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -377,8 +388,8 @@ def main():
     # certifies whole images with all their draws, no vote all-reduce; 16 bytes per image come back).  Same sample indices as the
     # timed region, so the (label, radius) list must be the same list.  Outside the timed region; reported beside the headline.
     image_sharded = None
-    if world > 1 and not rgf and not gen:
-        sm2 = cg.Smooth(base, NUM_CLASSES, SIGMA, seed=42)
+    if collective and not rgf and not gen:
+        sm2 = cg.Smooth(base, NUM_CLASSES, SIGMA, seed=42, force_collective=forced)
         sm2.certify_images(images[:min(world, len(images))], n_sel, n_est, ALPHA, per_gpu)      # untimed: first use of this path
         sm2.reset(args.warmup * (n_sel + n_est))                                             # the cursor of the timed region
         torch.cuda.synchronize()
@@ -471,7 +482,7 @@ def main():
         line = {
             "metric": "certified images/sec (N=100, sigma=0.5)", "value": value, "unit": "certified images/s",
             "n_gpus": world,
-            "rccl_ranks": (ranks_report["summed_ranks"] if backend == "nccl" else 0) if world > 1 else 1,
+            "rccl_ranks": (ranks_report["summed_ranks"] if backend == "nccl" else 0) if collective else 1,
             "collective_backend": backend or "none (single rank)",
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
@@ -541,7 +552,7 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     clf.close()
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

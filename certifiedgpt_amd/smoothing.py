@@ -46,7 +46,7 @@ class Smooth(object):
     ABSTAIN = -1  # smoothing.py:17
 
     def __init__(self, base_classifier, num_classes: int, sigma: float, seed: int = 0, process_group=None,
-                 device_stats: bool = False, non_certifiable=()):
+                 device_stats: bool = False, non_certifiable=(), force_collective=None):
         """
         :param base_classifier: an engine exposing `sample_counts(x, first_sample, num, batch_size, sigma, seed)`
                (certifiedgpt_amd.HipClassifier), or any callable mapping a [B,C,H,W] CUDA tensor to [B,num_classes]
@@ -59,6 +59,10 @@ class Smooth(object):
                G images' statistics on the host (one copy of the [G,2,K] table)
         :param non_certifiable: class ids that are not classes of the certificate (the "other" bucket of an answer
                vocabulary, agents/label_adapter.py): certify / predict return ABSTAIN when such a class comes out on top
+        :param force_collective: run the vote all-reduce also in a process group of ONE rank (a SUM over one rank is the identity,
+               so results do not change): lets a one-GPU box execute the RCCL path -- `dist.all_reduce` of the CUDA int64 histograms
+               through backend "nccl" -- that a world of 1 otherwise skips.  Default: the environment variable
+               CGPT_FORCE_COLLECTIVE=1, else off.  Ignored when torch.distributed is not initialised.
         """
         self.base_classifier = base_classifier
         self.num_classes = num_classes
@@ -67,6 +71,10 @@ class Smooth(object):
         self.process_group = process_group
         self.device_stats = bool(device_stats)
         self.non_certifiable = frozenset(int(c) for c in non_certifiable)
+        if force_collective is None:
+            import os
+            force_collective = os.environ.get("CGPT_FORCE_COLLECTIVE", "") not in ("", "0")
+        self.force_collective = bool(force_collective)
         self._next_sample = 0
         self._lib = _lib.lib()
         self._timing = None                                # see collect_timing()
@@ -100,6 +108,15 @@ class Smooth(object):
         t["compute"].append((e0, e1))
         t["calls"] += 1
         return out
+
+    def _reduces(self, world: int) -> bool:
+        """Does this `_sample_noise` end in the collective?  Always with more than one rank; with one rank only on request."""
+        if world > 1:
+            return True
+        if not self.force_collective:
+            return False
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
 
     def _all_reduce(self, counts):
         """The ONE collective of a `_sample_noise` (C1): SUM of the int64 vote histograms over the ranks."""
@@ -149,7 +166,7 @@ class Smooth(object):
         with torch.no_grad():
             counts = self._timed_compute(lambda: self.base_classifier.sample_counts_pair(
                 x, first + lo_a, hi_a - lo_a, first + n0 + lo_b, hi_b - lo_b, batch_size, float(self.sigma), self.seed))
-        if world > 1:
+        if self._reduces(world):
             self._all_reduce(counts)
         if self.device_stats and counts.is_cuda:
             return counts, None                            # histograms stay on the device (certify finishes there)
@@ -175,7 +192,7 @@ class Smooth(object):
         with torch.no_grad():
             counts = self._timed_compute(lambda: bc.sample_counts_images(xs, first + lo_a, hi_a - lo_a, first + n0 + lo_b, hi_b - lo_b,
                                                                           n0 + n, float(self.sigma), self.seed))
-        if world > 1:
+        if self._reduces(world):
             self._all_reduce(counts)
         c = counts.cpu().numpy().astype(int)
         return [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(G)]
@@ -199,7 +216,7 @@ class Smooth(object):
             c = c.cpu().numpy().astype(int)
             mine = [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(hi - lo)]
             table[lo:hi] = torch.tensor(mine, dtype=torch.float64).to(table.device)
-        if world > 1:
+        if self._reduces(world):
             self._all_reduce(table)                        # rows of the other ranks are zero here: the SUM is a gather
         t = table.cpu().numpy()
         return [(int(t[i, 0]), float(t[i, 1])) for i in range(G)]
@@ -220,7 +237,7 @@ class Smooth(object):
             c = c.cpu().numpy().astype(int)
             table[lo:hi] = torch.tensor([float(self.predict_from_counts(c[i, 0], alpha)) for i in range(hi - lo)],
                                         dtype=torch.float64).to(table.device)
-        if world > 1:
+        if self._reduces(world):
             self._all_reduce(table)
         return [self._predicted(int(v)) for v in table.cpu().numpy()]
 
@@ -263,7 +280,7 @@ class Smooth(object):
         with torch.no_grad():
             counts = self._timed_compute(lambda: bc.sample_counts_images(xs, first + lo, hi - lo, 0, 0, stride, float(self.sigma),
                                                                           self.seed))[:, 0].contiguous()
-        if world > 1:
+        if self._reduces(world):
             self._all_reduce(counts)
         return counts.cpu().numpy().astype(int)
 
@@ -292,7 +309,7 @@ class Smooth(object):
         lo, hi = shard_range(num, rank, world)
         with torch.no_grad():
             counts = self._timed_compute(lambda: self._local_counts(x, first + lo, hi - lo, batch_size))
-        if world > 1:
+        if self._reduces(world):
             self._all_reduce(counts)                       # the one collective (C1)
         return counts
 

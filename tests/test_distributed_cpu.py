@@ -265,3 +265,49 @@ def test_answer_vocabulary_is_rank_independent_and_growth_is_refused():
         assert p.exitcode == 0
     assert got[0][1] == got[1][1] == single                          # same ids on every rank: the all-reduce sums like with like
     assert all("would grow under torch.distributed" in g[2] for g in got)
+
+
+def _forced_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        calls = {"n": 0}
+        real = dist.all_reduce
+
+        def counting(t, *a, **kw):
+            calls["n"] += 1
+            return real(t, *a, **kw)
+        dist.all_reduce = counting
+        xs = torch.zeros(3, 3, 8, 8)
+
+        def everything(s):
+            return (s.certify(xs[0], 51, 77, 0.01, 16), int(s.predict(xs[0], 125, 0.001, 32)), s._sample_noise(xs[0], 40, 8).tolist(),
+                    s.certify_many(xs, 51, 77, 0.01, 16), s.certify_images(xs, 51, 77, 0.01, 16))
+        plain = everything(cg.Smooth(ImagesEngine(), K, 0.5, seed=11))
+        n_plain = calls["n"]
+        forced = everything(cg.Smooth(ImagesEngine(), K, 0.5, seed=11, force_collective=True))
+        q.put((plain == forced, n_plain, calls["n"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_force_collective_runs_the_all_reduce_in_a_world_of_one():
+    """`force_collective=True` (or CGPT_FORCE_COLLECTIVE=1): a process group of ONE rank still ends every `_sample_noise` in the
+    all-reduce -- the switch tests/test_gpu_distributed.py uses to run the RCCL path on a one-GPU box.  Results are unchanged,
+    and without torch.distributed initialised the switch does nothing."""
+    s = cg.Smooth(ImagesEngine(), K, 0.5, seed=11, force_collective=True)
+    assert s._reduces(1) is False and s._reduces(2) is True           # no process group in this process
+    os.environ["CGPT_FORCE_COLLECTIVE"] = "1"
+    try:
+        assert cg.Smooth(ImagesEngine(), K, 0.5).force_collective is True
+    finally:
+        del os.environ["CGPT_FORCE_COLLECTIVE"]
+    assert cg.Smooth(ImagesEngine(), K, 0.5).force_collective is False
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    same, n_plain, n_total = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same is True and n_plain == 0 and n_total == 5

@@ -123,6 +123,103 @@ def test_two_ranks_two_gpus_rccl_match_single_process():
     assert got[0][1][0] == single[0] and got[0][1][1] == int(single[1]) and got[0][1][2] == single[2]
 
 
+def _nccl_one_rank(port, q):
+    """The product's collective path through backend "nccl" (= RCCL) on the hardware a one-GPU box has: a process group of ONE
+    rank.  A world of 1 normally skips the collective (smoothing.py `_reduces`), so `force_collective=True` makes every
+    `_sample_noise` end in `dist.all_reduce` of its CUDA int64 histogram -- the call the driver's 8-GPU run makes (launch.py:110-120
+    starts one process per device; SURVEY.md 8(e): one all-reduce of the vote counts)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import certifiedgpt_amd as cg
+    from oracle import model_oracle as mo
+    from gpu_util import tiny_pair, DEV
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        K, G = 10, 3
+        clf, p16, params, cfg = tiny_pair(mo.MODE_ENCODE_IMG, num_classes=K, max_batch=32)
+        x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+        xs = torch.stack([x0, x0 * 0.5, x0 + 0.3])
+        plain = cg.Smooth(clf, K, 0.25, seed=5)                           # world of 1: no collective
+        forced = cg.Smooth(clf, K, 0.25, seed=5, force_collective=True)   # same draws, every histogram through RCCL
+        assert not plain._reduces(1) and forced._reduces(1)
+        calls = {"n": 0}
+        real = dist.all_reduce
+
+        def counting(t, *a, **kw):
+            assert t.is_cuda and t.dtype in (torch.int64, torch.float64)
+            calls["n"] += 1
+            return real(t, *a, **kw)
+        dist.all_reduce = counting
+        try:
+            def everything(s):
+                return (s.certify(x0, 25, 39, 0.05, 32), int(s.predict(x0, 30, 0.05, 7)), s._sample_noise(x0, 11, 4).tolist(),
+                        s.certify_many(xs, 9, 11, 0.05, 32), s.certify_images(xs, 9, 11, 0.05, 32),
+                        [int(v) for v in s.predict_images(xs, 30, 0.05, 7)])
+            a = everything(plain)
+            assert calls["n"] == 0
+            b = everything(forced)
+            n_calls = calls["n"]
+        finally:
+            dist.all_reduce = real
+        # Smooth._all_reduce itself on the [G,2,K] table of certify_many, with the timing hooks bench.py uses
+        forced.collect_timing(True)
+        table = (torch.arange(G * 2 * K, dtype=torch.int64, device=DEV).reshape(G, 2, K) * 7 - 3)
+        want = table.clone()
+        forced._all_reduce(table)
+        dist.barrier(device_ids=[0])
+        torch.cuda.synchronize()
+        tm = forced.timing()
+        ones = torch.ones(1, device=DEV, dtype=torch.int64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        q.put({"equal": a == b, "calls": n_calls, "table_ok": bool(torch.equal(table, want)), "backend": dist.get_backend(),
+               "world": dist.get_world_size(), "summed": int(ones.item()), "allreduce_ms": tm["allreduce_ms"],
+               "allreduce_host_ms": tm["allreduce_host_ms"]})
+        clf.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nccl_product_path_runs_on_one_gpu():
+    """the first time RCCL sees the product's all-reduce must not be the 8-GPU run.  One spawned rank (started
+    before this process touches the GPU path of the child), backend "nccl", world_size 1: certify / predict / _sample_noise /
+    certify_many / certify_images / predict_images with the collective forced give exactly the results of the same calls without
+    it, and each of them really went through dist.all_reduce on a CUDA tensor."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert got["backend"] == "nccl" and got["world"] == 1 and got["summed"] == 1
+    assert got["equal"] is True and got["table_ok"] is True
+    assert got["calls"] == 6, got                       # one collective per call: certify, predict, _sample_noise, certify_many, 2 x images
+    assert got["allreduce_ms"] >= 0.0 and got["allreduce_host_ms"] > 0.0
+
+
+def test_bench_ranks_block_over_nccl_on_one_gpu():
+    """`CGPT_BENCH_FORCE_NCCL=1 python bench.py --gpus 1`: bench.py's whole multi-rank code path (process group "nccl", barrier with
+    device_ids, MAX over ranks, per-rank timing gather, SUM of ones, image-sharded pass) on a world of one rank."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, CGPT_BENCH_FORCE_NCCL="1", CGPT_BENCH_NO_SUSTAINED="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["collective_backend"] == "nccl" and line["rccl_ranks"] == 1
+    rk = line["ranks"]
+    assert rk["summed_ranks"] == 1 and len(rk["per_rank_ms"]) == 1
+    assert rk["per_rank_ms"][0]["sample_noise_calls"] >= 1 and rk["per_rank_ms"][0]["all_reduce_host"] > 0
+    assert line["image_sharded"]["equals_sample_sharded"] is True
+    assert line["value"] > 0
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no WORLD_SIZE starts its two ranks itself (a child `torch.distributed.run`) and reports
     n_gpus = 2; on this one-GPU box as a rehearsal (both ranks on cuda:0, gloo), so rccl_ranks is 0 and says so.  A request for
