@@ -64,6 +64,39 @@ def host_cores():
     return max(1, min(cores, int(os.environ.get("CGPT_CPU_THREADS", "16"))))
 
 
+def cpu_headline_leg(clf, x, cores):
+    """Like for like with the headline: ONE whole `Smooth.certify(x, n0=100, n=100, alpha=0.001, batch_size=10)` at sigma = 0.5 on the
+    CPU oracle (smoothing.py:29-56 restated, fp32 ViT-G + head, this run's weights, image and the GPU's own noise draws), timed; the
+    same call on the GPU for the comparison of the two results.  200 fp32 ViT-G forwards: ~100 s on 16 cores (--cpu-baseline-headline)."""
+    import numpy as np
+    import certifiedgpt_amd as cg
+    from oracle import model_oracle as mo, smooth_oracle as so
+    seed = 4242
+    cfg = mo.Config(mode=mo.MODE_VIT_HEAD, num_classes=NUM_CLASSES)
+    params = {name: torch.from_numpy(clf.get_weight(name)).reshape(shape) for name, shape in mo.param_shapes(cfg).items()}
+    torch.set_num_threads(cores)
+    gpu_label, gpu_radius = cg.Smooth(clf, NUM_CLASSES, SIGMA, seed=seed).certify(x, N0, N, ALPHA, 100)
+    draws = cg.noise_batch(torch.zeros_like(x), 0, N0 + N, 1.0, seed).cpu().numpy()
+    done = {"n": 0}
+
+    def classifier(batch):
+        out = mo.forward_all(params, torch.from_numpy(np.ascontiguousarray(batch)), cfg)["logits"].numpy()
+        done["n"] += len(batch)
+        print(f"bench.py: cpu headline leg {done['n']}/{N0 + N} forwards", file=sys.stderr, flush=True)   # a progress line every ~5 s
+        return out
+
+    oracle = so.SmoothOracle(classifier, NUM_CLASSES, SIGMA, lambda first, num, shape: draws[first:first + num])
+    t0 = time.perf_counter()
+    cpu_label, cpu_radius = oracle.certify(x.cpu().numpy(), N0, N, ALPHA, 10)
+    cpu_s = time.perf_counter() - t0
+    return {"headline_certify_s": cpu_s, "headline_images_per_s": 1.0 / cpu_s,
+            "headline_sample": f"one whole Smooth.certify of the headline config itself (n0={N0}, n={N}, sigma={SIGMA}, alpha={ALPHA}: "
+                               f"{N0 + N} fp32 ViT-G forwards in batches of 10 on {cores} threads), same weights / image / noise draws as "
+                               f"the GPU call it is compared with",
+            "headline_result_cpu": [int(cpu_label), float(cpu_radius)], "headline_result_gpu": [int(gpu_label), float(gpu_radius)],
+            "headline_label_equal": int(cpu_label) == int(gpu_label), "headline_abs_dR": abs(float(cpu_radius) - float(gpu_radius))}
+
+
 def cpu_baseline_and_parity(clf, x):
     """BASELINE configs[0] on both sides, in this run: ONE whole `Smooth.certify(x, n0=10, n=10, alpha=0.001, batch_size=10)`
     at sigma = 0.25 (a) timed on the host cores with the CPU oracle (oracle/smooth_oracle.py around the fp32 PyTorch-CPU
@@ -143,6 +176,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # the CPU leg on the headline config itself (n0 = n = 100, sigma = 0.5: ~100 s of host time) beside the default configs[0] leg
+    ap.add_argument("--cpu-baseline-headline", action="store_true")
     # extra data points (NOT the headline line): BASELINE configs[2] without the Vicuna decode, and the reference's own 448^2 size
     ap.add_argument("--workload", choices=["vit_head", "encode_img", "rgf", "minigpt4"], default="vit_head")
     ap.add_argument("--img-size", type=int, default=224)
@@ -205,6 +240,9 @@ def main():
     if os.environ.get("CGPT_GEMM_ABLATE"):          # measurement-only switches of experimental code paths
         from certifiedgpt_amd import _lib
         _lib.check(cg.lib().cgpt_set_option(b"gemm_ablate", int(os.environ["CGPT_GEMM_ABLATE"])))
+    if os.environ.get("CGPT_BENCH_ONLY_TIMED", "") not in ("", "0"):   # profiling runs: bounded number of dispatches in flight
+        from certifiedgpt_amd import _lib
+        _lib.check(cg.lib().cgpt_set_option(b"sync_batches", 1))
     dev = torch.device("cuda", local)
     # certify runs its n0 + n draws as ONE fused pass; the largest per-rank share of it is one batch
     def _share(r):
@@ -331,7 +369,8 @@ def main():
         newest = cands[-1]                                             # the newest round directory that holds a summary
         with open(newest) as f:
             summ = json.load(f)
-        pm, meta = summ["fc1"], summ.get("_meta", {})
+        # the row whose launches are all full batches of `per_gpu` samples (tools/pmc_summary.py profiles a run made of nothing else)
+        pm, meta = summ.get("fc1_full_batch") or summ["fc1"], summ.get("_meta", {})
         rel = os.path.relpath(newest, ROOT)
         lib_sha = hashlib.sha256(open(cg._lib.LIB_PATH, "rb").read()).hexdigest()[:16]
         if not (world == 1 and headline):
@@ -339,17 +378,23 @@ def main():
         elif FC1_KERNEL not in pm.get("kernel_name", ""):
             traffic_note = "PMC summary %s (commit %s) is for kernel %r, not %s: traffic withheld" % (
                 rel, meta.get("git_head"), pm.get("kernel_name"), FC1_KERNEL)
-        elif meta.get("batch_size_per_gpu") != per_gpu:
-            traffic_note = "PMC summary %s was taken at batch %s, this run uses %d: traffic withheld" % (rel, meta.get("batch_size_per_gpu"), per_gpu)
+        elif pm.get("batch_samples", meta.get("batch_size_per_gpu")) != per_gpu:
+            traffic_note = "PMC summary %s was taken at batch %s, this run uses %d: traffic withheld" % (
+                rel, pm.get("batch_samples", meta.get("batch_size_per_gpu")), per_gpu)
         else:
             traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
             same = meta.get("libcgpt_sha256_16") == lib_sha
             # MFMA busy fraction and shader clock of the same kernel in the profiled run: busy x clock / 2.4 GHz reproduces `frac`
             pmc_fc1 = {"mfma_busy_frac": pm.get("mfma_busy_frac"), "clock_ghz": pm.get("clock_ghz"), "l2_hit_rate": pm.get("l2_hit_rate"),
-                       "source": rel, "same_build": same}
+                       "source": rel, "same_build": same, "launches": pm.get("launches"), "avg_us_unprofiled_pass": pm.get("avg_us"),
+                       "frac_from_profile": pm.get("frac_of_peak"),
+                       "note": "mfma_busy_frac and clock_ghz belong to the PROFILED run (a --pmc pass holds other clocks than this run): their "
+                               "product / 2.4 GHz is that pass's frac, not this run's; this run's own pair is in_kernel_clock_ghz and "
+                               "implied_mfma_busy_frac"}
             traffic_note = ("bytes per launch of %s from %s, taken at commit %s (%s this run's libcgpt.so; rocprofv3 --pmc FETCH_SIZE / "
                             "WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted): read %.0f MB + "
-                            "write %.0f MB vs algorithmic %.0f MB (A %.0f + W %.0f + out %.0f; full %d-sample batches)" % (
+                            "write %.0f MB vs algorithmic %.0f MB (A %.0f + W %.0f + out %.0f); counters and algorithmic bytes are both for "
+                            "full %d-sample batches" % (
                                 FC1_KERNEL, rel, meta.get("git_head"),
                                 "the same build as" if same else "a DIFFERENT build than",
                                 pm["hbm_read_bytes_corrected"] / 1e6, pm["hbm_write_bytes"] / 1e6,
@@ -372,7 +417,8 @@ def main():
     # The reference-shaped call, outside the timed region: ONE Smooth.certify(x, n0, n, alpha, batch_size = n0 + n) per image
     # (smoothing.py:29-56), i.e. no grouping of images; every rank takes part (its shard + the all-reduce).
     single_ms = None
-    if not rgf:
+    only_timed = os.environ.get("CGPT_BENCH_ONLY_TIMED", "") not in ("", "0")   # profiling runs (tools/pmc_summary.py): nothing but the
+    if not rgf and not only_timed:                                              # timed region's full batches reaches the GPU
         reps = 3
         smooth.certify(images[0], n_sel, n_est, ALPHA, n_sel + n_est)
         torch.cuda.synchronize()
@@ -412,7 +458,7 @@ def main():
     # The yardstick beside the data-sheet peak: the dense fp16 MFMA rate THIS device sustains on random operands with nothing else
     # running (cgpt_mfma_sustained: MFMA-only loop, ~2 s, clock settled first), measured after everything else, rank 0 of a 1-GPU run only.
     sustained = None
-    if world == 1 and rank == 0 and headline and not os.environ.get("CGPT_BENCH_NO_SUSTAINED"):
+    if world == 1 and rank == 0 and headline and not os.environ.get("CGPT_BENCH_NO_SUSTAINED") and not only_timed:
         import ctypes as C
         tf, ghz = C.c_double(), C.c_double()
         if cg.lib().cgpt_mfma_sustained(2.0, C.byref(tf), C.byref(ghz)) == 0:
@@ -450,7 +496,7 @@ def main():
         # of the largest logit; tests/test_gpu_fullsize.py measures the noise itself): every DECISIVE row must give the identical answer
         with torch.no_grad():
             ho = llm.generate(inputs_embeds=embs, attention_mask=torch.ones(embs.shape[:2], dtype=torch.int, device=dev),
-                              max_new_tokens=20, output_scores=True, return_dict_in_generate=True, **base.generate_kwargs)
+                              max_new_tokens=20, output_scores=True, return_dict_in_generate=True, **base.hf_generate_kwargs())
             h_tok, h_sc = ho.sequences, torch.stack(ho.scores, dim=1).float()
             eps = 4.0 * fp16_ulp(float(h_sc[torch.isfinite(h_sc)].abs().max()))
             par_gr = greedy_decode_parity(h_tok, h_sc, gr._generate_graph(embs), eps)
@@ -501,9 +547,11 @@ def main():
                          "achieved": fc1_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": fc1_tflops / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "in_kernel_clock_ghz": fc1_clock,
+                         "implied_mfma_busy_frac": (fc1_tflops / MFMA_PEAK_TFLOPS) * 2.4 / fc1_clock if fc1_clock else None,
                          "in_kernel_clock_note": "shader clock this kernel held in THIS run: d(s_memtime) / d(s_memrealtime) x 100 MHz summed over all "
-                                                 "workgroups of its launches in the timed region (the data sheet's peak assumes 2.4 GHz): frac = "
-                                                 "MFMA-busy fraction x this / 2.4",
+                                                 "workgroups of its launches in the timed region (the data sheet's peak assumes 2.4 GHz); "
+                                                 "implied_mfma_busy_frac = frac x 2.4 / this clock = the share of THIS run's cycles in which the "
+                                                 "matrix pipes would have to be issuing to deliver `achieved`",
                          "launches": fc1_n, "avg_launch_ms": fc1_ms / max(fc1_n, 1),
                          "flop_per_launch": fc1_flops / max(fc1_n, 1),
                          "all_gemms": {"achieved": all_tflops, "frac": all_tflops / MFMA_PEAK_TFLOPS, "launches": all_n,
@@ -548,6 +596,9 @@ def main():
             try:
                 line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(clf, images[0])
                 line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+                if args.cpu_baseline_headline:
+                    line["cpu_baseline"].update(cpu_headline_leg(clf, images[0], line["cpu_baseline"]["cores"]))
+                    line["gpu_over_cpu_headline"] = value / line["cpu_baseline"]["headline_images_per_s"]
             except Exception as e:  # the CPU leg must never void the GPU measurement
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)

@@ -69,12 +69,14 @@ class CertifyLoop:
                 else:
                     print(f"{idx}\t{label}\t{pred}\t{rec['correct']}\t{dt:.3f}", file=f, flush=True)
 
-        # images_per_pass > 1 (certify only): Smooth.certify_many runs the per-rank sample slices of several images in one
-        # classifier batch and one all-reduce -- the multi-GPU throughput mode; results equal the one-by-one loop.
-        by_image = sm_cfg.get("shard", "samples") == "images"
+        shard = sm_cfg.get("shard", "samples")
+        if shard not in ("samples", "images"):
+            raise ValueError(f"run.smoothing.shard must be 'samples' or 'images', not {shard!r}")
+        # Grouping of images.  shard = samples (certify only): Smooth.certify_many runs the per-rank sample slices of `images_per_pass`
+        # images in one classifier batch and one all-reduce -- the multi-GPU throughput mode.  shard = images (certify AND predict):
+        # groups of images_per_pass x world images, whole images per rank.  Results equal the one-by-one loop either way.
+        by_image = shard == "images"
         group = int(sm_cfg.get("images_per_pass", 1)) if (mode == "certify" or by_image) else 1
-        if sm_cfg.get("shard", "samples") not in ("samples", "images"):
-            raise ValueError(f"run.smoothing.shard must be 'samples' or 'images', not {sm_cfg.get('shard')!r}")
         if by_image:                                       # SURVEY.md 8(e), the zero-communication mode: whole images per rank
             from ..smoothing import _world
             group = max(group, 1) * _world(smooth.process_group)[1]
@@ -84,7 +86,8 @@ class CertifyLoop:
             if not pending:
                 return
             t0 = time.perf_counter()
-            xs = torch.stack([p[1] for p in pending])
+            # image-sharded: hand over the list -- Smooth stacks only this rank's own slice of it; sample-sharded: every rank needs all
+            xs = [p[1] for p in pending] if by_image else torch.stack([p[1] for p in pending])
             if mode != "certify":                          # predict agent, image-sharded
                 outs = [(lab, 0.0) for lab in smooth.predict_images(xs, sm_cfg["n"], sm_cfg["alpha"], sm_cfg["batch_size"])]
             else:

@@ -43,45 +43,67 @@ __global__ __launch_bounds__(512) void mfma_sustained_kernel(float* out, unsigne
 
 }  // namespace
 
-// Runs the loop back to back for `seconds` (the first 3/4 settle the clock, the last 1/4 is timed).  Synchronous; allocates and frees
-// its own 0.5 MB.  tflops: dense fp16 MFMA rate; clock_ghz: in-kernel d(s_memtime) / d(s_memrealtime) x 100 MHz.
+// Runs the loop back to back for `seconds` (the first 3/4 settle the clock, the last 1/4 is timed) on the CURRENT device's null stream -- the
+// caller selects the device (hipSetDevice / torch.cuda.set_device) first.  Synchronous; allocates and frees its own 0.5 MB.
+// tflops: dense fp16 MFMA rate; clock_ghz: in-kernel d(s_memtime) / d(s_memrealtime) x 100 MHz.  Every HIP call is checked: a launch that
+// fails (e.g. a code object for another architecture) is an error, never a zero-duration "measurement".
 hipError_t run_mfma_sustained(double seconds, double* tflops, double* clock_ghz) {
+    if (tflops) *tflops = 0.0;
+    if (clock_ghz) *clock_ghz = 0.0;
     int dev = 0, cus = 256;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
     float* out = nullptr;
     unsigned long long* clk = nullptr;
-    if (hipError_t e = hipMalloc(&out, (size_t)cus * 512 * sizeof(float)); e != hipSuccess) return e;
-    if (hipError_t e = hipMalloc(&clk, (size_t)cus * 2 * sizeof(unsigned long long)); e != hipSuccess) { (void)hipFree(out); return e; }
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t err = hipSuccess;
+    auto cleanup = [&](hipError_t code) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (out) (void)hipFree(out);
+        if (clk) (void)hipFree(clk);
+        return code;
+    };
+#define CGPT_DIAG_TRY(call) do { err = (call); if (err != hipSuccess) return cleanup(err); } while (0)
+    CGPT_DIAG_TRY(hipMalloc(&out, (size_t)cus * 512 * sizeof(float)));
+    CGPT_DIAG_TRY(hipMalloc(&clk, (size_t)cus * 2 * sizeof(unsigned long long)));
+    CGPT_DIAG_TRY(hipMemset(clk, 0, (size_t)cus * 2 * sizeof(unsigned long long)));
+    CGPT_DIAG_TRY(hipEventCreate(&e0));
+    CGPT_DIAG_TRY(hipEventCreate(&e1));
     const int iters = 20000;                                                // 16 MFMAs per iteration and wave: ~3 ms per launch
     const double flop = (double)cus * 8.0 * iters * 16.0 * (2.0 * 16 * 16 * 32);
-    auto launch = [&] { hipLaunchKernelGGL(mfma_sustained_kernel, dim3(cus), dim3(512), 0, 0, out, clk, iters, 12345u); };
-    launch();
-    (void)hipEventRecord(e0); launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
-    float one = 1.f;
-    (void)hipEventElapsedTime(&one, e0, e1);
-    if (one <= 0.f) one = 1.f;
+    auto launch = [&]() -> hipError_t {
+        hipLaunchKernelGGL(mfma_sustained_kernel, dim3(cus), dim3(512), 0, 0, out, clk, iters, 12345u);
+        return hipGetLastError();
+    };
+    CGPT_DIAG_TRY(launch());
+    CGPT_DIAG_TRY(hipDeviceSynchronize());                                  // the first launch ran (faults surface here)
+    CGPT_DIAG_TRY(hipEventRecord(e0));
+    CGPT_DIAG_TRY(launch());
+    CGPT_DIAG_TRY(hipEventRecord(e1));
+    CGPT_DIAG_TRY(hipEventSynchronize(e1));
+    float one = 0.f;
+    CGPT_DIAG_TRY(hipEventElapsedTime(&one, e0, e1));
+    if (!(one > 0.f)) return cleanup(hipErrorUnknown);
     if (seconds < 0.2) seconds = 0.2;
     const int warm = (int)(seconds * 750.0 / one) + 1, timed = (int)(seconds * 250.0 / one) + 1;
-    for (int i = 0; i < warm; ++i) launch();
-    (void)hipEventRecord(e0);
-    for (int i = 0; i < timed; ++i) launch();
-    (void)hipEventRecord(e1);
-    hipError_t err = hipEventSynchronize(e1);
-    float ms = 1.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
+    for (int i = 0; i < warm; ++i) CGPT_DIAG_TRY(launch());
+    CGPT_DIAG_TRY(hipEventRecord(e0));
+    for (int i = 0; i < timed; ++i) CGPT_DIAG_TRY(launch());
+    CGPT_DIAG_TRY(hipEventRecord(e1));
+    CGPT_DIAG_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CGPT_DIAG_TRY(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> h((size_t)cus * 2);
-    if (err == hipSuccess) err = hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    CGPT_DIAG_TRY(hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#undef CGPT_DIAG_TRY
     double cyc = 0, real = 0;
     for (int i = 0; i < cus; ++i) { cyc += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
+    if (!(ms > 0.f) || !(real > 0)) return cleanup(hipErrorUnknown);      // no time elapsed or no workgroup wrote its clock: not a measurement
     if (tflops) *tflops = flop * timed / (ms * 1e-3) / 1e12;
-    if (clock_ghz) *clock_ghz = real > 0 ? cyc / real * 0.1 : 0.0;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(out); (void)hipFree(clk);
-    return err;
+    if (clock_ghz) *clock_ghz = cyc / real * 0.1;
+    return cleanup(hipSuccess);
 }
 
 }  // namespace cgpt

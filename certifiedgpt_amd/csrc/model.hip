@@ -544,6 +544,12 @@ static cgpt_status check_call(cgpt_handle h, const void* p1, const void* p2, int
     return CGPT_OK;
 }
 
+// cgpt_set_option("sync_batches", 1): wait for the stream after every classifier batch of the sample_counts* entry points.  Measurement aid:
+// a profiler that keeps one record per dispatch in flight (rocprofv3 --pmc) runs out of room when one call enqueues tens of thousands of
+// dispatches without a host synchronisation (40 batches x ~400 kernels at 51 images per cgpt_sample_counts_images call).  Never changes a result.
+static int g_sync_batches = 0;
+#define CGPT_BATCH_DONE(st) do { if (g_sync_batches) HIPCHK(hipStreamSynchronize(st)); } while (0)
+
 cgpt_status cgpt_sample_counts(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num, int64_t batch_size,
                                float sigma, uint64_t noise_seed, int64_t* counts_dev, void* stream) {
     CGCHK(check_call(h, x_dev, counts_dev, num, "cgpt_sample_counts"));
@@ -556,6 +562,7 @@ cgpt_status cgpt_sample_counts(cgpt_handle h, const float* x_dev, int64_t first_
         const int nb = (int)((num - done < batch_size) ? (num - done) : batch_size);
         CGCHK(forward(h, x_dev, true, first_sample + done, nb, 0, nb, sigma, noise_seed, st));
         HIPCHK(launch_vote(h->logits, h->K, nb, h->K, counts_dev, nb, counts_dev, st));
+        CGPT_BATCH_DONE(st);
         done += nb;
     }
     return CGPT_OK;
@@ -579,6 +586,7 @@ cgpt_status cgpt_sample_counts2(cgpt_handle h, const float* x_dev, int64_t first
         const int64_t fb = first_b + (done > num_a ? done - num_a : 0);
         CGCHK(forward(h, x_dev, true, fa, na, fb, nb, sigma, noise_seed, st));
         HIPCHK(launch_vote(h->logits, h->K, nb, h->K, counts_a_dev, na, counts_b_dev, st));
+        CGPT_BATCH_DONE(st);
         done += nb;
     }
     return CGPT_OK;
@@ -599,6 +607,7 @@ cgpt_status cgpt_sample_counts_images(cgpt_handle h, const float* x_dev, int64_t
         const int nb = (int)((total - r0 < h->cfg.max_batch) ? (total - r0) : h->cfg.max_batch);
         CGCHK(forward(h, x_dev, true, first_a, (int)num_a, first_b, nb, sigma, noise_seed, st, (int)per, image_stride, r0));
         HIPCHK(launch_vote(h->logits, h->K, nb, h->K, counts_dev, num_a, counts_dev + h->K, st, (int)per, r0));
+        CGPT_BATCH_DONE(st);
     }
     return CGPT_OK;
 }
@@ -793,6 +802,7 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
         g_gemm_ablate = value;
         return CGPT_OK;
     }
+    if (k == "sync_batches") { g_sync_batches = value != 0; return CGPT_OK; }
 #ifdef CGPT_LAB
     if (k == "gemm_group_m") { if (value < 1) return cgpt_fail(CGPT_ERR_INVALID, "gemm_group_m >= 1"); g_gemm_group_m = value; return CGPT_OK; }
 #endif

@@ -207,7 +207,7 @@ class MiniGPT4Classifier:
         self.last_answers = []
         # decode = "hf": `llama_model.generate(...)` exactly as the reference calls it (minigpt_base.py:418-431).
         # decode = "graph": the same greedy decode -- the model's own forward for the prefill and for every step, a DynamicCache, EOS
-        #   suppressed on the first token where the installed `generate` does so (min_length = 1: _hf_min_length), pad after EOS -- written as a fixed-length loop without host round trips and
+        #   suppressed on the first `min_length` generated tokens (the reference's semantics, see hf_generate_kwargs), pad after EOS -- written as a fixed-length loop without host round trips and
         #   replayed from ONE hipGraph per (batch, prompt length); shared prompts on a HIP device only, everything else takes "hf".
         #   Parity with HF generate (tests/test_gpu_fullsize.py, Vicuna-7B widths, 200 rows x 20 tokens): run eagerly the loop gives HF's
         #   tokens and logits bit for bit; under graph capture other vendor kernels get picked, so logits move by fp16 rounding and a row
@@ -224,7 +224,6 @@ class MiniGPT4Classifier:
         self._graphs = collections.OrderedDict()            # LRU of captured decode graphs, see _generate_graph
         self.max_graphs = 4
         self._eos_mask = None
-        self._min_length_minus_prompt = None                # see _hf_min_length
         self.decode_stats = {"graph_replays": 0, "graph_captures": 0, "graph_evictions": 0, "hf_calls": 0, "hf_fallback_kwargs": 0}
 
     # ---- nn.Module-shaped surface used by Smooth (smoothing.py:42,71)
@@ -285,7 +284,7 @@ class MiniGPT4Classifier:
             if self.decode == "graph" and shared and embs.is_cuda:
                 self.decode_stats["hf_fallback_kwargs"] += 1            # generation arguments outside the greedy whitelist
             outputs = self.llama_model.generate(inputs_embeds=embs, attention_mask=attn_mask, max_new_tokens=self.max_new_tokens,
-                                                **self.generate_kwargs)
+                                                **self.hf_generate_kwargs())
         return self._decode_outputs(outputs)
 
     def _decode_outputs(self, outputs):
@@ -302,34 +301,57 @@ class MiniGPT4Classifier:
     # sampling and with one beam HF ignores it).  Anything else -- eos_token_id, stopping_criteria, no_repeat_ngram_size,
     # bad_words_ids, min_new_tokens, max_length, logits_processor, ... -- takes the HF path, so the same classifier never decodes
     # differently by `decode=`.
-    _GREEDY_NEUTRAL = {"num_beams": 1, "do_sample": False, "repetition_penalty": 1, "min_length": 1, "top_p": None,
+    _GREEDY_NEUTRAL = {"num_beams": 1, "do_sample": False, "repetition_penalty": 1, "min_length": None, "top_p": None,
                        "temperature": None, "length_penalty": None, "top_k": None}
+    # fields of the checkpoint's own `generation_config` (generation_config.json; `generate` merges it under the call's arguments) that
+    # create a logits processor, a stopping rule or another decoding mode, with the values at which they do nothing
+    _CONFIG_NEUTRAL = {"repetition_penalty": (None, 1, 1.0), "no_repeat_ngram_size": (None, 0), "encoder_no_repeat_ngram_size": (None, 0),
+                       "encoder_repetition_penalty": (None, 1, 1.0), "bad_words_ids": (None,), "suppress_tokens": (None,),
+                       "begin_suppress_tokens": (None,), "forced_bos_token_id": (None,), "forced_eos_token_id": (None,),
+                       "sequence_bias": (None,), "min_new_tokens": (None, 0), "num_beams": (None, 1), "num_beam_groups": (None, 1),
+                       "do_sample": (None, False), "penalty_alpha": (None, 0, 0.0), "exponential_decay_length_penalty": (None,),
+                       "renormalize_logits": (None, False), "remove_invalid_values": (None, False), "guidance_scale": (None, 1, 1.0),
+                       "watermarking_config": (None,), "prompt_lookup_num_tokens": (None,), "stop_strings": (None,),
+                       "diversity_penalty": (None, 0, 0.0), "max_time": (None,), "dola_layers": (None,)}
 
     def _greedy_defaults(self):
+        """May this call take the fixed-length greedy loop?  Only when every argument of the call AND every field of the model's own
+        generation_config (which `generate` applies wherever the call is silent) is one the loop reproduces; otherwise the HF path
+        runs, so the same classifier never decodes differently by `decode=`."""
         for key, val in self.generate_kwargs.items():
             if key not in self._GREEDY_NEUTRAL:
                 return False
             want = self._GREEDY_NEUTRAL[key]
             if want is not None and val != want:
                 return False
+        gen = getattr(self.llama_model, "generation_config", None)
+        if gen is not None:
+            for key, neutral in self._CONFIG_NEUTRAL.items():
+                if key in self.generate_kwargs:                        # the call's argument wins over the checkpoint's field
+                    continue
+                val = getattr(gen, key, None)
+                if isinstance(val, (list, tuple, dict)) and len(val) == 0:
+                    val = None
+                if val not in neutral:
+                    return False
         return True
 
-    def _hf_min_length(self, prompt_len):
-        """The `min_length` HF `generate` really applies to a call with `inputs_embeds` (the reference passes min_length = 1,
-        minigpt_base.py:385).  transformers 4.30.0 -- the reference's pin, docker/tpu-docker:32 -- counts generated tokens only, so EOS
-        is suppressed on the first token; later versions subtract the embedded prompt's length (`GenerationMixin.
-        _prepare_generated_length`: max(min_length - inputs_embeds.shape[1], 0)), which turns min_length = 1 into 0.  The greedy loop
-        follows whatever the INSTALLED generate does, so decode="graph" and decode="hf" are the same decode in either environment."""
-        ml = int(self.generate_kwargs.get("min_length", 1) or 0)
-        if self._min_length_minus_prompt is None:
-            import inspect
-            try:
-                from transformers.generation.utils import GenerationMixin
-                src = inspect.getsource(GenerationMixin._prepare_generated_length)
-                self._min_length_minus_prompt = ("min_length - inputs_tensor.shape[1]" in src) or ("min_length -= inputs_tensor.shape[1]" in src)
-            except Exception:
-                self._min_length_minus_prompt = False
-        return max(ml - int(prompt_len), 0) if self._min_length_minus_prompt else ml
+    def min_new_tokens(self):
+        """Generated tokens before which EOS is suppressed.  The reference passes `min_length = 1` with `inputs_embeds`
+        (minigpt_base.py:385) to transformers 4.30.0 (its pin, docker/tpu-docker:32), which counts GENERATED tokens in that call: the
+        first token is never EOS and an answer is never empty.  Later versions subtract the embedded prompt's length from min_length
+        (5.15: `_prepare_generated_length`, max(min_length - inputs_embeds.shape[1], 0) = 0).  This class ships the REFERENCE's
+        semantics on both decode paths, whatever transformers is installed."""
+        return int(self.generate_kwargs.get("min_length", 1) or 0)
+
+    def hf_generate_kwargs(self):
+        """`generate_kwargs` as handed to the installed `generate`: the reference's `min_length` travels as `min_new_tokens`, which
+        means "generated tokens" in every transformers version (and takes precedence over min_length where both exist)."""
+        kw = dict(self.generate_kwargs)
+        ml = kw.pop("min_length", None)
+        if ml and "min_new_tokens" not in kw:
+            kw["min_new_tokens"] = int(ml)
+        return kw
 
     def greedy_tokens(self, embs, return_logits=False):
         """What `generate(inputs_embeds=embs, attention_mask=ones, max_new_tokens=n, do_sample=False, min_length=1, ...)` returns for
@@ -375,16 +397,18 @@ class MiniGPT4Classifier:
         pos = torch.arange(L, device=embs.device).unsqueeze(0)
         out = llm(inputs_embeds=embs, position_ids=pos, past_key_values=cache, use_cache=True, logits_to_keep=1)
         logits = out.logits[:, -1, :].float()
-        if eos_ids and self._hf_min_length(L) > 0:                     # MinLengthLogitsProcessor: no EOS on the first token
+        min_new = self.min_new_tokens() if eos_ids else 0              # MinNewTokensLengthLogitsProcessor: no EOS on the first tokens
+        if min_new > 0:
             key = (str(embs.device), logits.shape[-1])
             if self._eos_mask is None or self._eos_mask[0] != key:     # built outside any capture (the warm-up run comes first)
                 m = torch.zeros(logits.shape[-1], dtype=torch.bool)
                 m[eos_ids] = True
                 self._eos_mask = (key, m.to(embs.device))
-            logits = logits.masked_fill(self._eos_mask[1], float("-inf"))
         unfinished = torch.ones(B, dtype=torch.long, device=embs.device)
         tokens, step_logits = [], []
         for i in range(self.max_new_tokens):
+            if i < min_new:
+                logits = logits.masked_fill(self._eos_mask[1], float("-inf"))
             if return_logits:
                 step_logits.append(logits)
             nxt = logits.argmax(dim=-1)

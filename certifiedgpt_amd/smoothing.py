@@ -198,21 +198,22 @@ class Smooth(object):
         return [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(G)]
 
     def certify_images(self, xs, n0: int, n: int, alpha: float, batch_size: int):
-        """`certify` for a stack of images xs[G,3,H,W], IMAGE-sharded (SURVEY.md 8(e), the zero-communication throughput mode;
+        """`certify` for a stack of images xs[G,3,H,W] (or a sequence of G image tensors), IMAGE-sharded (SURVEY.md 8(e), the zero-communication throughput mode;
         launch.py:110-120 starts one process per device): rank r certifies images shard_range(G, r, world) with ALL n0 + n draws
         of each -- no vote histogram leaves the rank -- and the G (label, radius) pairs, 16 bytes per image, are then summed
         into every rank's copy of the result table (the only collective; on one rank there is none).  Image i draws the sample
         indices the i-th of G consecutive `certify` calls would use, so the list equals that of `certify_many` and of the
         one-by-one loop on any number of ranks (counts bit-identical, statistics the same float64 code)."""
-        G = int(xs.shape[0])
+        G = len(xs)
         first = self._next_sample
         self._next_sample += G * (n0 + n)
         rank, world = _world(self.process_group)
         lo, hi = shard_range(G, rank, world)
-        table = torch.zeros(G, 2, dtype=torch.float64, device=xs.device)
+        mine_xs, dev = self._own_images(xs, lo, hi)
+        table = torch.zeros(G, 2, dtype=torch.float64, device=dev)
         if hi > lo:
             with torch.no_grad():
-                c = self._timed_compute(lambda: self._counts_of_images(xs[lo:hi], first + lo * (n0 + n), n0, n, batch_size))
+                c = self._timed_compute(lambda: self._counts_of_images(mine_xs, first + lo * (n0 + n), n0, n, batch_size))
             c = c.cpu().numpy().astype(int)
             mine = [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(hi - lo)]
             table[lo:hi] = torch.tensor(mine, dtype=torch.float64).to(table.device)
@@ -225,21 +226,36 @@ class Smooth(object):
         """`predict` (smoothing.py:58-79) for a stack of images, image-sharded like `certify_images`: rank r takes whole images,
         image i draws the n indices the i-th of G consecutive `predict` calls would use; the labels (ABSTAIN = -1 included) are
         exchanged at 8 bytes per image.  Returns a list of numpy.int64 / ABSTAIN exactly as G `predict` calls return them."""
-        G = int(xs.shape[0])
+        G = len(xs)
         first = self._next_sample
         self._next_sample += G * n
         rank, world = _world(self.process_group)
         lo, hi = shard_range(G, rank, world)
-        table = torch.zeros(G, dtype=torch.float64, device=xs.device)
+        mine_xs, dev = self._own_images(xs, lo, hi)
+        table = torch.zeros(G, dtype=torch.float64, device=dev)
         if hi > lo:
             with torch.no_grad():
-                c = self._timed_compute(lambda: self._counts_of_images(xs[lo:hi], first + lo * n, n, 0, batch_size))
+                c = self._timed_compute(lambda: self._counts_of_images(mine_xs, first + lo * n, n, 0, batch_size))
             c = c.cpu().numpy().astype(int)
             table[lo:hi] = torch.tensor([float(self.predict_from_counts(c[i, 0], alpha)) for i in range(hi - lo)],
                                         dtype=torch.float64).to(table.device)
         if self._reduces(world):
             self._all_reduce(table)
         return [self._predicted(int(v)) for v in table.cpu().numpy()]
+
+    @staticmethod
+    def _own_images(xs, lo: int, hi: int):
+        """(this rank's images [hi-lo,3,H,W] or None, device of the result table).  `xs` is a stacked tensor [G,3,H,W] or a SEQUENCE of G
+        image tensors: with a sequence only the rank's own slice is stacked (an agent that walks a dataset need not materialise the
+        other ranks' images on its GPU -- entries outside [lo, hi) are never touched and may be None)."""
+        if isinstance(xs, torch.Tensor):
+            return (xs[lo:hi] if hi > lo else None), xs.device
+        own = [xs[i] for i in range(lo, hi)]
+        if own:
+            return torch.stack(own), own[0].device
+        ref = next((t for t in xs if isinstance(t, torch.Tensor)), None)
+        return None, (ref.device if ref is not None else torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                      else torch.device("cpu"))
 
     def _counts_of_images(self, xs, first: int, n0: int, n: int, batch_size) -> torch.Tensor:
         """int64 [g, 2, K]: selection and estimation histograms of g images, every draw on THIS rank; image i uses the indices

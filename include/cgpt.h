@@ -217,16 +217,25 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
 /* The shader clock the profiled GEMMs of `kind` (as above; 0 = all) actually ran at: every workgroup of the 256-row kernels reads
  * s_memtime and s_memrealtime at its first and last instruction while profiling is on; clock_ghz = sum of cycles / sum of 100-MHz
  * ticks x 0.1 (0 when nothing was profiled).  Synchronises the device.  Read it BEFORE cgpt_profile_read(kind 0), which resets
- * the sums with the log.  roofline.frac = MFMA-busy fraction x this clock / 2.4 GHz, so a clock give-back shows up here. */
+ * the sums with the log.  For ONE run, frac = (share of cycles in which the matrix pipes issue) x this clock / 2.4 GHz, so a clock
+ * give-back shows up here; bench.py prints that share as roofline.implied_mfma_busy_frac.  (roofline.pmc.mfma_busy_frac and .clock_ghz
+ * come from a separate rocprofv3 --pmc run, which holds other clocks: never multiply numbers of the two runs.) */
 cgpt_status cgpt_profile_clock(cgpt_handle h, int32_t kind, double* clock_ghz);
 
 /* Process-wide SPEED knobs.  No option changes a result: every accepted value gives bit-identical outputs (tested).
+ * THREADING OF THE LIBRARY (not only of a handle): these options AND the per-device first-launch caches of the kernel launchers (LDS
+ * attribute + CU count, set on a device's first launch of each kernel) are process-global and unsynchronised.  One thread drives the
+ * library until every device in use has run its first forward; afterwards handles on DIFFERENT devices may be driven from different
+ * threads (one thread per handle), and options are set only while no launch is in flight.  The supported deployment is the reference's:
+ * one process per GPU (launch.py:110-120).
  *   "gemm_kernel": 0 = automatic choice (default); 1 = 128x128 register-staged tile, 3 = 256x128 direct-to-LDS tile,
  *                  4 = 256x256 phase-alternating tile, 14 = 256x256 two-phase quadrant tile with a 1.5-K-tile LDS-DMA run-ahead (the
  *                  automatic choice for M >= 1024 when the shape has more than 128 tiles of 256x256).
  *   "gemm_ablate": TEST-ONLY bit mask; each bit turns ONE optimisation of the 256x256 kernels off without changing a result, so that
  *                  the test suite can check that the bits do not depend on it: 512 = LDS-transposed fp16 epilogue, 16384 = 192-column
  *                  last tiles for N = 256k+128.  Any other bit is rejected with CGPT_ERR_INVALID.  Process-global and unsynchronised: set it only while no launch is in flight.
+ *   "sync_batches": MEASUREMENT aid; 1 = cgpt_sample_counts* wait for the stream after every classifier batch (a --pmc profiler keeps a
+ *                  record per in-flight dispatch and one call can enqueue tens of thousands); 0 (default) = nothing is synchronised.
  * (A lab build of the library -- make LAB=1, never shipped -- additionally accepts the experimental schedules 2, 5..11, 15 and
  * timing-study switches that skip work; profiles/r01/gemm_variants.txt.) */
 cgpt_status cgpt_set_option(const char* key, int32_t value);
@@ -234,7 +243,9 @@ cgpt_status cgpt_set_option(const char* key, int32_t value);
 /* Measurement aid (no counterpart in the reference): the dense fp16 MFMA rate THIS device sustains on random operands when it does nothing
  * else -- v_mfma_f32_16x16x32_f16 back to back from registers for `seconds` (clock settled first), in TFLOP/s, and the in-kernel shader
  * clock in GHz.  The data sheet's 2.5 PFLOP/s assumes 2.4 GHz; under an MFMA-dense load an MI355X holds 1.8-1.95 GHz, so bench.py reports
- * a kernel's fraction of the data-sheet peak AND of this rate (profiles/r04/mfma_sustained.txt).  Synchronous; uses the default stream. */
+ * a kernel's fraction of the data-sheet peak AND of this rate (profiles/r04/mfma_sustained.txt).  Synchronous; runs on the null stream of
+ * the CURRENT device: select the device first (hipSetDevice / torch.cuda.set_device).  Every HIP call inside is checked: a failed launch,
+ * a zero elapsed time or an unwritten clock buffer returns an error (outputs 0), never a number. */
 cgpt_status cgpt_mfma_sustained(double seconds, double* tflops_out, double* clock_ghz_out);
 
 /* ---- raw kernels exported for unit tests and reuse (all fp16 operands are IEEE binary16) ----

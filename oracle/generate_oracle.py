@@ -44,10 +44,13 @@ def generate(llama_model, tokenizer, img_embeds, texts, num_beams=1, max_new_tok
         emb_len = emb.shape[1]
         embs[i, -emb_len:] = emb[0]
         attn_mask[i, -emb_len:] = 1
+    # :418-431.  The reference passes `min_length=min_length`; its pinned transformers (4.30.0, docker/tpu-docker:32) counts GENERATED
+    # tokens for an inputs_embeds call, later versions subtract the embedded prompt's length (5.15: min_length 1 -> 0).  `min_new_tokens`
+    # says "generated tokens" in every version, so the oracle states the reference's semantics independently of what is installed.
     outputs = llama_model.generate(inputs_embeds=embs, attention_mask=attn_mask, max_new_tokens=max_new_tokens,
                                    num_beams=num_beams, length_penalty=length_penalty, temperature=temperature,
-                                   do_sample=do_sample, min_length=min_length, top_p=top_p,
-                                   repetition_penalty=repetition_penalty)                       # :418-431
+                                   do_sample=do_sample, min_new_tokens=min_length, top_p=top_p,
+                                   repetition_penalty=repetition_penalty)
     answers = []
     for output_token in outputs:                                                                # :441-448
         if output_token[0] == 0:

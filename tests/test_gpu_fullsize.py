@@ -158,6 +158,63 @@ def test_vitg_headline_certify_n100_sigma05_matches_cpu_oracle(vitg_pair):
     print(f"[vitg headline] abstain gpu {gpu_out[0] == cg.Smooth.ABSTAIN} oracle {ora_out[0] == so.ABSTAIN}, |dR| {abs(gpu_out[1] - ora_out[1]):.3e}")
 
 
+def test_vitg_configs4_rgf_attack_at_its_stated_size(vitg_pair):
+    """BASELINE configs[4] at its stated size: 8-step RGF perturbation (1 direction per step) x smoothed `predict` with N = 100 at
+    sigma = 0.5 on ViT-G + head, 224 x 224 -- 1 700 classifier forwards per attacked image.
+    PARITY UNPINNED (no reference code): the reference describes its attack stage in prose only (README.md:62-64,108-120), so the
+    schedule is this build's own rule and what this test pins is the product (HIP noise / classifier / vote / update kernels + the
+    host loop of certifiedgpt_amd/rgf.py) against oracle/rgf_oracle.attack -- the numpy statement of the same rule -- fed the
+    device's own direction draws and the GPU's vote shares (the pattern of tests/test_gpu_parity.py at tiny size).  Bit-exact:
+    the adversarial image, the share history and the final smoothed label; plus reproducibility, the eps ball and the cursor
+    arithmetic that makes `forwards_per_image` 1 700."""
+    from oracle import rgf_oracle as ro
+    clf, cfg, params = vitg_pair
+    x0 = torch.from_numpy(mo.synthetic_image(cfg)).to(DEV)
+    sigma, seed, n, alpha, bs = 0.5, 42, 100, 0.001, clf.max_batch
+    steps, q, delta, lr, eps, dseed = 8, 1, 0.5, 0.05, 0.25, 1234              # bench.py --workload rgf
+    s = cg.Smooth(clf, K, sigma, seed=seed)
+    base_counts = s._sample_noise(x0, n, bs)
+    # the runner-up of the clean image's vote (a share that can move); class 1 (bench.py's target) when the vote is unanimous
+    target = int(np.argsort(base_counts)[-2]) if int((base_counts > 0).sum()) > 1 else 1
+    start = 1000
+
+    def run():
+        s.reset(start)
+        atk = cg.RGFAttack(s, steps=steps, num_dirs=q, delta=delta, lr=lr, eps=eps, dir_seed=dseed)
+        assert atk.forwards_per_image(n) == 1700
+        out = atk.attack(x0, target, n, alpha, bs, targeted=True)
+        assert atk._next_dir == steps * q and s._next_sample == start + (steps + 1) * n     # 9 evaluations' worth of fresh draws
+        return out
+
+    t0 = time.perf_counter()
+    x_adv, label, hist = run()
+    torch.cuda.synchronize()
+    t_attack = time.perf_counter() - t0
+    x_adv2, label2, hist2 = run()
+    assert torch.equal(x_adv, x_adv2) and label == label2 and hist == hist2     # reproducible bit for bit
+    assert len(hist) == steps + 1 and all(0.0 <= h <= 1.0 for h in hist)
+    assert float((x_adv - x0).abs().max()) <= eps + 1e-6
+    assert label == cg.Smooth.ABSTAIN or 0 <= label < K
+
+    def share_fn(img, step):                                                    # the sample indices RGFAttack uses in that step
+        s.reset(start + step * n)
+        c = s._sample_noise(torch.from_numpy(np.ascontiguousarray(img)).to(DEV), n, bs)
+        return float(c[target]) / n
+
+    def direction_fn(i):                                                        # the device's own draws
+        return cg.noise_batch(torch.zeros_like(x0), i, 1, 1.0, dseed)[0].cpu().numpy()
+
+    o_adv, o_hist = ro.attack(share_fn, direction_fn, x0.cpu().numpy(), steps, q, delta, lr, eps, targeted=True)
+    assert o_hist == hist, (o_hist, hist)
+    assert np.array_equal(o_adv, x_adv.cpu().numpy())
+    # the final label is `predict`'s decision rule on the last evaluation's histogram (smoothing.py:73-79), CPU statistics oracle
+    s.reset(start + steps * n)
+    final_counts = s._sample_noise(x_adv, n, bs)
+    assert label == so.predict_from_counts(final_counts, alpha)
+    print(f"[vitg configs4] target {target}, share history {hist}, final label {label}, one attacked image {t_attack:.2f} s "
+          f"at batch {bs} (parity unpinned: no reference code)")
+
+
 # ------------------------------------------------------------------ full-size encode_img (configs[2] minus the Vicuna decode)
 @pytest.fixture(scope="module")
 def encode_img_pair():
@@ -305,7 +362,7 @@ def test_configs2_graph_decode_and_cgpt_prefill_follow_hf_generate_at_vicuna_wid
     embs = torch.cat([segs[0].expand(B, -1, -1), emb, segs[1].expand(B, -1, -1)], dim=1)
     with torch.no_grad():
         out = llm.generate(inputs_embeds=embs, attention_mask=torch.ones(embs.shape[:2], dtype=torch.int, device=DEV), max_new_tokens=n,
-                           output_scores=True, return_dict_in_generate=True, **hf.generate_kwargs)
+                           output_scores=True, return_dict_in_generate=True, **hf.hf_generate_kwargs())
     hf_tokens, hf_scores = out.sequences, torch.stack(out.scores, dim=1).float()
     ulp = fp16_ulp(float(hf_scores[torch.isfinite(hf_scores)].abs().max()))
     gr = MiniGPT4Classifier(enc, llm, tok, prompt, lm, max_new_tokens=n, max_batch=B, decode="graph")

@@ -151,9 +151,9 @@ def test_reference_decode_cleanup_goldens(golden):
 PROMPT = prepare_texts(["<Img><ImageHere></Img> [vqa] what is shown here"])[0]
 
 
-def _classifier(num_classes=8, vocabulary=()):
-    return MiniGPT4Classifier(StubEncoder(), tiny_llama(), ToyTokenizer(), PROMPT, AnswerLabelMap(num_classes, vocabulary),
-                              max_new_tokens=6)
+def _classifier(num_classes=8, vocabulary=(), llm=None, generate_kwargs=None):
+    return MiniGPT4Classifier(StubEncoder(), llm if llm is not None else tiny_llama(), ToyTokenizer(), PROMPT,
+                              AnswerLabelMap(num_classes, vocabulary), max_new_tokens=6, generate_kwargs=generate_kwargs)
 
 
 def test_prompt_template_and_cleanup():
@@ -202,3 +202,60 @@ def test_one_hot_logits_follow_the_frozen_vocabulary():
     want = [vocab.index(a) if a in vocab else clf2.label_map.other_id for a in answers]
     assert logits.argmax(1).tolist() == want
     assert clf2.last_answers == answers[-len(clf2.last_answers):]
+
+
+def _eos_first_llm():
+    """A tiny decoder whose very first generated token would be EOS (and whose later ones are not): lm_head row of EOS boosted along
+    the direction of the prompt's last hidden state."""
+    from toy_llm import EOS
+    llm = tiny_llama(hidden=64, seed=7)
+    clf = _classifier(llm=llm)
+    images = torch.randn(4, 3, 8, 8, generator=torch.Generator().manual_seed(3))
+    emb, _ = clf.encoder.encode_img(images)
+    segs = clf._segment_embeddings(PROMPT, emb.device)
+    embs = torch.cat([segs[0].expand(4, -1, -1), emb, segs[1].expand(4, -1, -1)], dim=1)
+    with torch.no_grad():
+        h = llm.model(inputs_embeds=embs).last_hidden_state[:, -1, :]                 # [4, hidden]: what the first logits are taken from
+        llm.lm_head.weight[EOS] += 50.0 * h.mean(0) / h.mean(0).norm()
+        first = llm(inputs_embeds=embs).logits[:, -1, :].argmax(-1)
+    assert bool((first == EOS).all())                                                 # without suppression every answer would be empty
+    return llm, emb, embs
+
+
+def test_first_token_is_never_eos_on_either_decode_path_whatever_transformers_is_installed():
+    """the reference's `min_length = 1` (minigpt_base.py:385) means "at least one GENERATED token" under its pinned
+    transformers 4.30.0; the installed 5.15 would turn it into 0 for an inputs_embeds call.  Both decode paths ship the reference's
+    semantics: HF `generate` gets it as min_new_tokens, the greedy loop masks EOS on the first step -- same tokens, no empty answer."""
+    from toy_llm import EOS
+    llm, emb, embs = _eos_first_llm()
+    clf = _classifier(llm=llm)
+    kw = clf.hf_generate_kwargs()
+    assert kw.get("min_new_tokens") == 1 and "min_length" not in kw and clf.min_new_tokens() == 1
+    with torch.no_grad():
+        hf = llm.generate(inputs_embeds=embs, attention_mask=torch.ones(embs.shape[:2], dtype=torch.int), max_new_tokens=6, **kw)
+        loop = clf.greedy_tokens(embs)
+    assert bool((hf[:, 0] != EOS).all()) and bool((loop[:, 0] != EOS).all())
+    assert torch.equal(loop[:, :hf.shape[1]], hf) or clf._decode_outputs(loop) == clf._decode_outputs(hf)
+    assert clf.generate_from_embeds(emb, PROMPT) == go.generate(llm, clf.llama_tokenizer, emb, [PROMPT] * 4, max_new_tokens=6)
+    # min_length = 0 switches the suppression off on both paths (then the first token IS EOS)
+    clf0 = _classifier(llm=llm, generate_kwargs={"min_length": 0})
+    assert clf0.min_new_tokens() == 0 and "min_new_tokens" not in clf0.hf_generate_kwargs()
+    with torch.no_grad():
+        assert bool((clf0.greedy_tokens(embs)[:, 0] == EOS).all())
+
+
+def test_checkpoint_generation_config_sends_the_call_down_the_hf_path():
+    """`generate` also applies the checkpoint's own generation_config (generation_config.json).  A field there that
+    creates a logits processor the greedy loop does not reproduce -- here no_repeat_ngram_size -- must disqualify the loop."""
+    llm = tiny_llama(hidden=64, seed=7)
+    clf = _classifier(llm=llm)
+    assert clf._greedy_defaults() is True
+    llm.generation_config.no_repeat_ngram_size = 2
+    assert clf._greedy_defaults() is False
+    llm.generation_config.no_repeat_ngram_size = 0
+    llm.generation_config.repetition_penalty = 1.3                    # overridden by the call's own repetition_penalty = 1: neutral
+    assert clf._greedy_defaults() is True
+    clf_rp = _classifier(llm=llm, generate_kwargs={"repetition_penalty": 1.3})
+    assert clf_rp._greedy_defaults() is False
+    llm.generation_config.suppress_tokens = [5]
+    assert clf._greedy_defaults() is False
