@@ -760,6 +760,7 @@ hipError_t launch_v3_epi(int epilogue, const GemmParams& p, hipStream_t stream) 
 
 int g_gemm_kernel = 0;
 int g_gemm_ablate = 0;
+int g_gemm_grid = 0;
 int g_gemm_group_m = 4;   // measured: 4 ~ 8 > 2 > 16 (profiles/r01/gemm_variants.txt)
 unsigned long long* g_gemm_dbg = nullptr;
 

@@ -404,7 +404,11 @@ hipError_t launch_v9(const GemmParams& p, hipStream_t stream) {
         configured[dev] = true;
     }
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const int grid = tiles < cus[dev] ? tiles : cus[dev];                   // one 512-thread workgroup per CU (LDS-limited), persistent
+    int grid = tiles < cus[dev] ? tiles : cus[dev];                         // one 512-thread workgroup per CU (LDS-limited), persistent
+    // cgpt_set_option("gemm_grid", n): at most n workgroups (a multiple of 8 keeps the XCD-aware walk), i.e. CUs left free for the
+    // kernels of ANOTHER stream (a workgroup of this kernel fills its CU's register file: nothing co-resides with it).  Any grid gives
+    // the same bits: a tile's arithmetic does not depend on which workgroup computes it.
+    if (g_gemm_grid > 0 && grid > g_gemm_grid) grid = g_gemm_grid;
     hipLaunchKernelGGL((gemm9_f16_kernel<EPI>), dim3(grid), dim3(512), lds_bytes, stream, p);
     return hipGetLastError();
 }

@@ -41,6 +41,7 @@ hipError_t launch_v8_epi(int epilogue, const GemmParams& p, hipStream_t stream);
 #endif
 extern int g_gemm_ablate;
 extern int g_gemm_group_m;
+extern int g_gemm_grid;      // 0 = one workgroup per CU; n > 0: at most n workgroups for the persistent 256x256 kernel (speed only)
 extern unsigned long long* g_gemm_dbg;
 extern int g_gemm_kernel;   // kernel override (speed only): 0 auto, 1 = 128x128, 3 = 256x128, 4 = 256x256 phased, 14 = 256x256 two-phase quadrant; lab builds: 2, 5..11, 15
 

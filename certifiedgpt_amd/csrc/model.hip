@@ -91,6 +91,7 @@ struct cgpt_model {
     bool pending_delta = false;   // CGPT_MODE_VIT_HEAD: the last block's fc2 output has been added to the CLS rows only
     bool profile = false;
     std::vector<ProfEvent> events;
+    std::vector<hipEvent_t> event_pool;      // timing-only events (hipEventDisableSystemFence), reused across profile_read(0) drains
     unsigned long long* clk_dev = nullptr;   // [8][2]: per GEMM kind, shader cycles and 100-MHz ticks summed over workgroups (cgpt_profile_clock)
 };
 
@@ -298,7 +299,13 @@ cgpt_status gemm(cgpt_model* m, int epi, const half_t* A, int64_t lda, const hal
     p.M = M; p.N = N; p.K = Kd; p.patches = m->P;
     ProfEvent ev;
     if (m->profile) {
-        HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
+        // timing-only events: no system-scope fence (cache write-back + invalidate) when they are recorded, which would slow down the
+        // GEMM that follows -- its A operand is the previous kernel's output, still in L2 / Infinity Cache -- and events come from a pool
+        auto take = [&](hipEvent_t* e) -> hipError_t {
+            if (!m->event_pool.empty()) { *e = m->event_pool.back(); m->event_pool.pop_back(); return hipSuccess; }
+            return hipEventCreateWithFlags(e, hipEventDisableSystemFence);
+        };
+        HIPCHK(take(&ev.a)); HIPCHK(take(&ev.b));
         HIPCHK(hipEventRecord(ev.a, st));
         if (m->clk_dev && kind >= 0 && kind < 8) p.clk = m->clk_dev + 2 * kind;
     }
@@ -463,6 +470,7 @@ cgpt_status cgpt_destroy(cgpt_handle h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : h->event_pool) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
     return CGPT_OK;
@@ -803,6 +811,11 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
         return CGPT_OK;
     }
     if (k == "sync_batches") { g_sync_batches = value != 0; return CGPT_OK; }
+    if (k == "gemm_grid") {
+        if (value < 0 || (value & 7)) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_grid must be 0 (one workgroup per CU) or a positive multiple of 8");
+        g_gemm_grid = value;
+        return CGPT_OK;
+    }
 #ifdef CGPT_LAB
     if (k == "gemm_group_m") { if (value < 1) return cgpt_fail(CGPT_ERR_INVALID, "gemm_group_m >= 1"); g_gemm_group_m = value; return CGPT_OK; }
 #endif
@@ -846,7 +859,7 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
         }
     }
     if (kind == 0) {   // reading "all" drains the log (and the in-kernel clock sums: every event has been synchronised above)
-        for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (auto& e : h->events) { h->event_pool.push_back(e.a); h->event_pool.push_back(e.b); }
         h->events.clear();
         if (h->clk_dev) HIPCHK(hipMemset(h->clk_dev, 0, 16 * sizeof(unsigned long long)));
     }
