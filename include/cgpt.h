@@ -234,6 +234,8 @@ cgpt_status cgpt_profile_clock(cgpt_handle h, int32_t kind, double* clock_ghz);
  *   "gemm_ablate": TEST-ONLY bit mask; each bit turns ONE optimisation of the 256x256 kernels off without changing a result, so that
  *                  the test suite can check that the bits do not depend on it: 512 = LDS-transposed fp16 epilogue, 16384 = 192-column
  *                  last tiles for N = 256k+128.  Any other bit is rejected with CGPT_ERR_INVALID.  Process-global and unsynchronised: set it only while no launch is in flight.
+ *   "gemm_grid":   0 (default) = one workgroup of the persistent 256x256 GEMM per CU; n > 0 (a multiple of 8) = at most n workgroups, i.e.
+ *                  CUs left free for kernels of another stream (tools/two_stream_probe.py; measured: no split beats the default).
  *   "sync_batches": MEASUREMENT aid; 1 = cgpt_sample_counts* wait for the stream after every classifier batch (a --pmc profiler keeps a
  *                  record per in-flight dispatch and one call can enqueue tens of thousands); 0 (default) = nothing is synchronised.
  * (A lab build of the library -- make LAB=1, never shipped -- additionally accepts the experimental schedules 2, 5..11, 15 and

@@ -139,6 +139,21 @@ def test_bad_arguments_return_status_not_crash():
     assert L.cgpt_destroy(None) == 0
 
 
+def test_process_wide_options_validate_their_values():
+    """cgpt_set_option needs no GPU: unknown keys and out-of-range values are status codes, accepted values round-trip to the default."""
+    L = cg.lib()
+    assert L.cgpt_set_option(b"no_such_option", 1) == 4 and b"unknown option" in L.cgpt_last_error()       # CGPT_ERR_NOT_FOUND
+    assert L.cgpt_set_option(None, 1) == 1
+    for bad in (-8, 7, 100):                                  # gemm_grid: 0 or a positive multiple of 8
+        assert L.cgpt_set_option(b"gemm_grid", bad) == 1, bad
+    for ok in (224, 8, 0):
+        assert L.cgpt_set_option(b"gemm_grid", ok) == 0, ok
+    assert L.cgpt_set_option(b"sync_batches", 1) == 0 and L.cgpt_set_option(b"sync_batches", 0) == 0
+    assert L.cgpt_set_option(b"gemm_kernel", 14) == 0 and L.cgpt_set_option(b"gemm_kernel", 0) == 0
+    assert L.cgpt_set_option(b"gemm_ablate", 1) in (0, 1)     # a wrong-result lab bit: rejected by the product library
+    assert L.cgpt_set_option(b"gemm_ablate", 0) == 0
+
+
 def test_allreduce_counts_rejects_bad_arguments_without_touching_rccl():
     """The C-level collective (include/cgpt.h): argument errors are status codes; a real all-reduce needs >= 2 GPUs (driver)."""
     L = cg.lib()

@@ -291,6 +291,37 @@ def test_linear_split_last_columns_is_bit_identical(M, N, K, epi):
     report(f"linear split {M}x{N}x{K} epi{epi}", outs[1][:M, :N].float().cpu(), ref, 2e-3 + 1e-3 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("epi", [0, 1, 3])
+def test_gemm_grid_option_is_bit_identical(epi):
+    """cgpt_set_option("gemm_grid", n): the persistent 256 x 256 kernel on fewer workgroups than CUs (CUs left to another stream's
+    kernels, tools/two_stream_probe.py).  A tile's arithmetic does not depend on the workgroup that computes it: same bits."""
+    L = cg.lib()
+    M, N, K = 4100, 4224, 256                                  # 17 x 17 tiles: more than 128, the two-phase kernel is picked
+    g = torch.Generator(device="cpu").manual_seed(91 + epi)
+    A = torch.zeros(ru(M, 256), K, dtype=torch.float16); A[:M] = (torch.randn(M, K, generator=g) * 0.5).half()
+    W = torch.zeros(ru(N, 256), K, dtype=torch.float16); W[:N] = (torch.randn(N, K, generator=g) * 0.1).half()
+    b = torch.randn(N, generator=g)
+    aux = torch.randn(M, N, generator=g).to(DEV) if epi == 3 else None
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    outs = []
+    try:
+        for grid in (0, 224, 64, 8):
+            out = torch.full((M, N), 7.0, device=DEV, dtype=torch.float16 if epi < 2 else torch.float32)
+            _lib.check(L.cgpt_set_option(b"gemm_grid", grid))
+            _lib.check(L.cgpt_linear_f16(P(Ad), K, P(Wd), K, P(bd), P(out), N, P(aux) if aux is not None else None, N, M, N, K, epi, stream()))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        _lib.check(L.cgpt_set_option(b"gemm_grid", 0))
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ref = A[:M].float() @ W[:N].float().t() + b
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 3:
+        ref = ref + aux.cpu()
+    report(f"linear gemm_grid {M}x{N}x{K} epi{epi}", outs[0].float().cpu(), ref, 2e-3 + 1e-3 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("epi", [0, 1])
 def test_fp16_epilogue_value_does_not_depend_on_kernel_or_tile_path(epi):
     """The same rows through (a) a small launch (M = 300: another kernel, guarded per-element epilogue with the scalar GELU) and
