@@ -58,6 +58,7 @@ SIGNATURES = {
     "cgpt_allreduce_counts": (_I32, [_P, _P, _I64, _P]),
     "cgpt_allreduce_counts_fn": (_I32, [_P, _P, _P, _I64, _P]),
     "cgpt_certify_from_counts": (_I32, [_P, _P, _I32, _I64, _D, _D, C.POINTER(_I32), C.POINTER(_D)]),
+    "cgpt_certify_many_from_counts": (_I32, [_P, _I64, _I32, _I64, _D, _D, _P, _P]),
     "cgpt_predict_from_counts": (_I32, [_P, _I32, _D, C.POINTER(_I32)]),
     "cgpt_certify_device": (_I32, [_P, _P, _I32, _I64, _D, _D, _P, _P]),
     "cgpt_predict_device": (_I32, [_P, _I32, _D, _P, _P]),

@@ -17,6 +17,19 @@ cgpt_status cgpt_certify_from_counts(const int64_t* counts_selection, const int6
     return CGPT_OK;
 }
 
+cgpt_status cgpt_certify_many_from_counts(const int64_t* counts, int64_t num_images, int32_t num_classes, int64_t n, double alpha,
+                                          double sigma, int32_t* labels_out, double* radii_out) {
+    if (!counts || !labels_out || !radii_out || num_images < 0 || num_classes < 1 || n < 1 || !(alpha > 0.0 && alpha < 1.0))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_certify_many_from_counts: bad argument");
+    for (int64_t i = 0; i < num_images; ++i) {
+        const int64_t* sel = counts + i * 2 * (int64_t)num_classes;
+        int label; double radius;
+        cgpt_stats::certify_from_counts(sel, sel + num_classes, num_classes, n, alpha, sigma, &label, &radius);
+        labels_out[i] = label; radii_out[i] = radius;
+    }
+    return CGPT_OK;
+}
+
 cgpt_status cgpt_predict_from_counts(const int64_t* counts, int32_t num_classes, double alpha, int32_t* label_out) {
     // the reference indexes top2[1] (smoothing.py:75): it needs at least two classes
     if (!counts || !label_out || num_classes < 2 || !(alpha > 0.0 && alpha < 1.0))

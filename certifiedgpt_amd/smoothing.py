@@ -194,8 +194,7 @@ class Smooth(object):
                                                                           n0 + n, float(self.sigma), self.seed))
         if self._reduces(world):
             self._all_reduce(counts)
-        c = counts.cpu().numpy().astype(int)
-        return [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(G)]
+        return [self._certifiable(r) for r in self.certify_many_from_counts(counts.cpu().numpy(), n, alpha)]
 
     def certify_images(self, xs, n0: int, n: int, alpha: float, batch_size: int):
         """`certify` for a stack of images xs[G,3,H,W] (or a sequence of G image tensors), IMAGE-sharded (SURVEY.md 8(e), the zero-communication throughput mode;
@@ -214,8 +213,7 @@ class Smooth(object):
         if hi > lo:
             with torch.no_grad():
                 c = self._timed_compute(lambda: self._counts_of_images(mine_xs, first + lo * (n0 + n), n0, n, batch_size))
-            c = c.cpu().numpy().astype(int)
-            mine = [self._certifiable(self.certify_from_counts(c[i, 0], c[i, 1], n, alpha)) for i in range(hi - lo)]
+            mine = [self._certifiable(r) for r in self.certify_many_from_counts(c.cpu().numpy(), n, alpha)]
             table[lo:hi] = torch.tensor(mine, dtype=torch.float64).to(table.device)
         if self._reduces(world):
             self._all_reduce(table)                        # rows of the other ranks are zero here: the SUM is a gather
@@ -371,6 +369,17 @@ class Smooth(object):
                                                       len(cs), int(n), float(alpha), float(self.sigma),
                                                       C.byref(label), C.byref(radius)))
         return int(label.value), float(radius.value)
+
+    def certify_many_from_counts(self, table, n: int, alpha: float):
+        """[(label, radius)] for a table of histograms [G, 2, K] (selection, estimation per image): one C call for the group."""
+        t = np.ascontiguousarray(table, dtype=np.int64)
+        if t.ndim != 3 or t.shape[1] != 2:
+            raise ValueError("certify_many_from_counts: table must be [G, 2, num_classes]")
+        G, K = int(t.shape[0]), int(t.shape[2])
+        labels, radii = np.empty(G, dtype=np.int32), np.empty(G, dtype=np.float64)
+        _lib.check(self._lib.cgpt_certify_many_from_counts(t.ctypes.data_as(C.c_void_p), G, K, int(n), float(alpha), float(self.sigma),
+                                                           labels.ctypes.data_as(C.c_void_p), radii.ctypes.data_as(C.c_void_p)))
+        return [(int(labels[i]), float(radii[i])) for i in range(G)]
 
     def _finalize_device(self, csel, cest, n, alpha, predict):
         out = torch.empty(2, dtype=torch.float64, device=cest.device)

@@ -89,6 +89,31 @@ def test_certify_from_counts_matches_reference_goldens(stats_golden):
     assert worst <= 1e-9                                  # what the implementation actually achieves
 
 
+def test_certify_many_from_counts_matches_reference_goldens(stats_golden):
+    """cgpt_certify_many_from_counts (one call for the group of images of Smooth.certify_many): every golden of the reference's own
+    `certify` again, grouped by (K, n, alpha, sigma) into tables [G, 2, K]; same decisions, same radii as the per-image entry point;
+    an empty group and a malformed table are handled."""
+    import collections
+    groups = collections.defaultdict(list)
+    for c in stats_golden["certify"]:
+        groups[(len(c["counts_sel"]), c["n"], c["alpha"], c["sigma"])].append(c)
+    checked = 0
+    for (K, n, alpha, sigma), cases in groups.items():
+        s = _smooth(sigma, K)
+        table = np.array([[c["counts_sel"], c["counts_est"]] for c in cases], dtype=np.int64)
+        out = s.certify_many_from_counts(table, n, alpha)
+        for c, (lab, rad) in zip(cases, out):
+            assert lab == c["label"] and abs(rad - c["radius"]) <= 1e-9, c
+            assert (lab, rad) == s.certify_from_counts(c["counts_sel"], c["counts_est"], n, alpha)
+        checked += len(cases)
+    assert checked == len(stats_golden["certify"]) and len(groups) > 3
+    s = _smooth(0.5, 7)
+    assert s.certify_many_from_counts(np.zeros((0, 2, 7), dtype=np.int64), 10, 0.001) == []
+    with pytest.raises(ValueError):
+        s.certify_many_from_counts(np.zeros((3, 7), dtype=np.int64), 10, 0.001)
+    assert cg.lib().cgpt_certify_many_from_counts(None, 1, 7, 10, 0.001, 0.5, None, None) == 1
+
+
 def test_predict_from_counts_matches_reference_goldens(stats_golden):
     for c in stats_golden["predict"]:
         s = _smooth(1.0, len(c["counts"]))
