@@ -11,8 +11,11 @@ estimation draws are independent, so `certify` runs them in the same classifier 
 every image -- into 255-sample classifier batches that are not aligned to image boundaries and sums all histograms of the group
 with one all-reduce (same sample indices, counts, labels and radii as K separate `certify` calls; tested).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
-    (extra, NON-headline data points: --workload encode_img | rgf, --img-size 448, --n 1000 / --n0 K)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--cpu-baseline-headline]
+    (extra, NON-headline data points: --workload encode_img | rgf | minigpt4, --img-size 448, --n 1000 / --n0 K)
+    environment: CGPT_BENCH_FORCE_NCCL=1 with --gpus 1 = the whole multi-rank code path over RCCL with a world of ONE rank (first contact
+    with the collective on a one-GPU box); CGPT_BENCH_ONLY_TIMED=1 = profiling runs (tools/pmc_summary.py): nothing but the timed region's
+    batches reaches the GPU, one stream synchronisation per classifier batch.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment is a self-contained N-rank run: this process -- before it touches
@@ -25,7 +28,8 @@ gemm9_f16_kernel<EPI_F16_GELU, true>, the two-phase quadrant kernel): achieved =
 events on the launch stream inside the timed region; `roofline.vit_gemms` lists the four ViT GEMM shapes the same way.
 `cpu_baseline` times ONE WHOLE Smooth.certify of BASELINE configs[0] (n0 = n = 10, sigma = 0.25) on the CPU oracle (oracle/, a port
 of the reference's Smooth + ViT-G forward in fp32 PyTorch) on the host cores, on rank 0 at N=1 only, and `parity` compares its
-(label, radius) and per-sample votes with the same call on the GPU.  `single_image_certify_ms` is the reference-shaped call.
+(label, radius) and per-sample votes with the same call on the GPU; --cpu-baseline-headline adds the headline config itself on the oracle
+(~100 s: `cpu_baseline.headline_certify_s`).  `single_image_certify_ms` is the reference-shaped call.
 """
 import argparse
 import json
