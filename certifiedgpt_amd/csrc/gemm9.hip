@@ -377,6 +377,10 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         d[0] = __builtin_amdgcn_s_memtime() - st_begin; d[1] = st_first; d[2] = st_loop; d[3] = st_epi;
         unsigned long long* e = p.dbg + (size_t)gridDim.x * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8;   // second table: phase stamps
         for (int k = 0; k < 8; ++k) e[k] = ph9[k];
+        if (wave == 0) {   // third table: [workgroup][begin, end] in 100-MHz real-time ticks (how evenly the workgroups finish)
+            unsigned long long* r = p.dbg + (size_t)gridDim.x * 8 * 12 + (size_t)blockIdx.x * 2;
+            r[0] = clk_r0; r[1] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 #endif
     if (p.clk && threadIdx.x == 0) {
