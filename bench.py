@@ -593,6 +593,8 @@ def main():
             line["forwards_per_s"] = value * fw
             if rgf:
                 line["metric"], line["unit"] = "attacked images/sec (8-step RGF, N=%d, sigma=0.5)" % n_est, "attacked images/s"
+                line["parity_note"] = ("parity unpinned: the reference has no attack code (README.md:62-64,108-120 is prose); the schedule is this "
+                                       "build's own rule, pinned bit-exactly against oracle/rgf_oracle.py only (tests/test_gpu_fullsize.py)")
             line.pop("vit_tflops_end_to_end", None)
             line["roofline"]["traffic"] = None
             line["roofline"]["flop_per_launch"] = fc1_flops / max(fc1_n, 1)
