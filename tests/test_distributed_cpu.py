@@ -311,3 +311,43 @@ def test_force_collective_runs_the_all_reduce_in_a_world_of_one():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert same is True and n_plain == 0 and n_total == 5
+
+
+def _list_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = cg.Smooth(ImagesEngine(), K, 0.5, seed=11)
+        G = 5
+        lo, hi = cg.shard_range(G, rank, world)
+        # a rank that walks a dataset only needs ITS images: the others' entries are never touched (None here)
+        xs = [torch.zeros(3, 8, 8) if lo <= i < hi else None for i in range(G)]
+        out = s.certify_images(xs, 51, 77, 0.01, 16)
+        pred = [int(v) for v in s.predict_images(xs, 125, 0.001, 32)]
+        q.put((rank, out, pred, s._next_sample))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_image_sharded_calls_accept_a_list_and_touch_only_the_ranks_own_images():
+    """in shard = images mode a rank need not materialise the other ranks' images.  `certify_images` / `predict_images` take a
+    SEQUENCE of image tensors and stack only the slice shard_range gives the rank -- entries outside it may even be None -- and still
+    return the list a stacked tensor gives on one rank."""
+    ref = cg.Smooth(ImagesEngine(), K, 0.5, seed=11)
+    xs = torch.zeros(5, 3, 8, 8)
+    want = ref.certify_images(xs, 51, 77, 0.01, 16)
+    want_pred = [int(v) for v in ref.predict_images(xs, 125, 0.001, 32)]
+    one = cg.Smooth(ImagesEngine(), K, 0.5, seed=11)
+    assert one.certify_images([xs[i] for i in range(5)], 51, 77, 0.01, 16) == want          # list form on one rank
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_list_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, pred, cursor in got:
+        assert out == want and pred == want_pred and cursor == ref._next_sample, (rank, out, want)
