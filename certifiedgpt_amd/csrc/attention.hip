@@ -26,6 +26,8 @@
 // ds_read_b128 lane groups (192-B rows: chunk 4ds+g -> 4ds + (g ^ ((-(row>>2))&3)); 128-B rows: c ^ ((row>>1)&7));
 // V rows have stride 224 B / 160 B: the 8 rows a 32-lane half reads by ds_read_b64_tr_b16 land on distinct 32-B windows.
 #include "kernels.h"
+#include <type_traits>
+#include <utility>
 
 namespace cgpt {
 
@@ -39,6 +41,34 @@ namespace {
 __device__ __forceinline__ f16x4 lds_read_tr16(const half_t* p) {
     fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(p));
     return __builtin_bit_cast(f16x4, v);
+}
+
+// The same read as an instruction the compiler cannot see into, for the streaming kernel.  hipcc's wait-count pass treats the tr-read
+// builtin (no memory operand) as a possible reader of every LDS-DMA request in flight and puts s_waitcnt vmcnt(0) in front of it: in
+// rounds 2-5 the V reads of a chunk's units 1 and 2 each waited until the requests for the NEXT chunk -- issued one unit earlier, into
+// the other buffer -- had landed (two memory latencies per chunk and wave; plain ds_read_b128 carry alias information and get no such
+// wait).  The kernel's own counted waits and chunk barriers are what orders requests and reads.  The compiler does not count these
+// reads in lgkmcnt either: lds_wait() in front of their first use; its own counted waits stay safe (LDS returns in order, uncounted
+// reads only make a wait longer).
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression (instruction offsets)
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// the same with `break`: f returns false to leave the loop (later iterations are not entered: the control flow of an unrolled loop)
+template <class F, int... I> __device__ __forceinline__ void static_for_while_impl(F&& f, std::integer_sequence<int, I...>) {
+    (void)(f(std::integral_constant<int, I>{}) && ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for_while(F&& f) { static_for_while_impl(f, std::make_integer_sequence<int, N>{}); }
+
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+template <int OFFSET_BYTES> __device__ __forceinline__ f16x4 lds_read_tr16_untracked(unsigned lds_addr) {
+    static_assert(OFFSET_BYTES >= 0 && OFFSET_BYTES < 65536, "16-bit instruction offset");
+    f16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFFSET_BYTES));
+    return v;
 }
 
 template <int DPAD> struct AttnLayout {
@@ -55,6 +85,20 @@ template <int DPAD> __device__ __forceinline__ int k_chunk_pos(int row, int ch) 
 #ifndef CGPT_ATT_PLAIN_WALK
 #define CGPT_ATT_PLAIN_WALK 0       // A/B builds: 1 = the round-robin (sample, head) walk of rounds 1-2
 #endif
+#ifndef CGPT_ATT_LONE_CARRIED
+#define CGPT_ATT_LONE_CARRIED 1     // A/B builds: 0 = rounds 2-5, a query block of its own for the lone query of Tq = 256 k + 1
+#endif
+
+// maximum over the four 16-lane groups of a wave.  The swaps' results go through scalars: __builtin_bit_cast applied to an ELEMENT of the
+// returned vector reads element 0 for both (hipcc 7.2), which silently reduced the maximum over lane group 0 only.
+__device__ __forceinline__ float max_over_lane_groups(float m) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    m = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+    const auto c2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    const unsigned c0 = c2[0], c1 = c2[1];
+    return fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
+}
 
 // HD: head_dim (88 | 64); DPAD: HD rounded up to 32; NKT: 16-key tiles held (keys padded to NKT*16); NT: threads.
 template <int HD, int DPAD, int NKT, int NT>
@@ -380,6 +424,15 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
 //     lane, then P.V);
 //   * the exponent reference lags the running maximum (see RESCALE_LOG2), so the 48 accumulator registers are rescaled a few times
 //     per pass instead of in nearly every unit.
+//   * Tq = 256 k + 1 (the CLS token on top of a 16 n x 16 n patch grid: T = 1025 at 448^2, the reference's image size) leaves ONE query
+//     for a block of its own.  As a block (rounds 2-5) it cost 0.76 of a full one -- 16 % of the kernel at T = 1025: wave 0 walked every
+//     key while seven waves issued requests; with its keys split over the eight waves it still cost 0.56, because a block with nothing to
+//     compute streams the pair's K and V at the latency of one 78-KB chunk in flight (profiles/r06/attention_stream_lone_query.txt).
+//     Now the pair's LAST FULL block carries it: at the end of every chunk, with the chunk still in LDS, wave (unit % 8) runs the lone
+//     query against ONE 32-key unit -- a 16-column tile whose columns all hold that query -- as an online softmax of its own whose
+//     state (O^T column, maximum, denominator: DPAD + 2 floats per wave) lives in LDS between chunks (no registers to spare: 238 of
+//     256); the eight partial softmaxes are merged after the block's last chunk.  No extra K / V traffic, four work items per pair,
+//     and the block that carries the query rotates over a workgroup's items (32 workgroups per XCD would otherwise pin it).
 // Work order: the query blocks of one (sample, head) re-read the same K and V (360 KB at T = 1025).  Workgroups are dealt to the 8
 // XCDs round-robin by the hardware, so XCD x owns the pairs x, x+8, ... and its workgroups walk pair-major through their query blocks:
 // the workgroups of one XCD sit on a few pairs at a time and K / V come out of that XCD's L2 (a plain item = blockIdx walk fetched a
@@ -400,7 +453,12 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r15 = lane & 15, g = lane >> 4;
-    const int nqb = (p.Tq + 255) / 256;
+    // query blocks per (sample, head); a lone last query rides on the last full block (see above)
+    const bool lone = CGPT_ATT_LONE_CARRIED && (p.Tq & 255) == 1 && p.Tq > 256;
+    const int nqb = lone ? p.Tq / 256 : (p.Tq + 255) / 256;
+    constexpr int RED_STRIDE = DPAD + 4;                                    // floats per wave: O^T column (16-byte rows), maximum, denominator
+    constexpr int RED_OFFSET = 2 * TKP * (KROW + VSTR) * (int)sizeof(half_t);   // bytes: behind the two chunk buffers
+    constexpr int QL_OFFSET = RED_OFFSET + 8 * RED_STRIDE * (int)sizeof(float);  // the lone query's B fragment, [chunk d / 8][8 halfs]
     const int nchunks = (p.Tk + TKP - 1) / TKP;
     // balanced chunks: CK keys each (a multiple of 32, <= TKP), so that every chunk's compute covers the next chunk's load
     const int CK = ((p.Tk + 31) / 32 + nchunks - 1) / nchunks * 32;
@@ -442,6 +500,9 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     const int my_pairs = by_sample ? ((p.B - xcd + 7) / 8) * p.heads : (npairs - xcd + nx - 1) / nx;
     const int nwork = my_pairs * nqb;
     auto pair_of = [&](int q) { return by_sample ? ((q / p.heads) * 8 + xcd) * p.heads + q % p.heads : xcd + nx * q; };   // = sample * heads + head
+    // work item w of this XCD -> query block of its pair w / nqb.  With a carried lone query the blocks of a pair are rotated by a number
+    // that grows with the pair, so that a workgroup (items lid, lid + nl, ...) meets the carrying block every nqb-th item and not always
+    auto qb_of = [&](int wi) { const int j = wi % nqb; return lone ? (j + (wi - j) / nl) % nqb : j; };
 
     // request chunk c of work item w into buffer `buf`: request r = wave + 8 i of the chunk covers slots 64 r .. 64 r + 63 of
     // the buffer image (K slots first); a lane fetches the 16-byte chunk that belongs in ITS slot, pad slots are skipped.
@@ -492,11 +553,14 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
 #define CGPT_S2STAMP(k)
 #endif
     // Q^T B-fragments of work item w's two tiles: lane holds Q[query r15][d = 32 ds + 8 g .. +7] (zero beyond HD).  They are requested
-    // in the LAST unit of the previous item -- every QK^T of that item has been issued by then -- so the load latency sits under that
-    // unit's softmax and P.V and the epilogue instead of in front of the item's first QK^T.
+    // behind the previous item's epilogue, all six loads together, then scaled and padded: one memory latency per item.  (Rounds 2-5
+    // asked for them inside the item's last unit as load-and-scale in one step, which hipcc emits as load, wait for EVERYTHING in
+    // flight, convert -- six memory latencies in a row in the middle of that unit.  Loading straight into qf there and scaling at the
+    // top of the next item makes every later use of qf in the unrolled unit loop wait for vmcnt(0), i.e. for the chunk requests; loads
+    // in front of the epilogue and the scaling behind it spill 26 registers.)
     f16x8 qf[2][NDS];
-    auto load_q = [&](int wi) {
-        const int pair = pair_of(wi / nqb), qb = wi % nqb;
+    auto load_q = [&](f16x8 (&qn)[2][NDS], int wi) {
+        const int pair = pair_of(wi / nqb), qb = qb_of(wi);
         const half_t* Qb = p.Q + (int64_t)(pair / p.heads) * p.q_batch_stride + (pair % p.heads) * HD;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -504,14 +568,22 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
                 const int d = min(ds * 32 + g * 8, HD - 8);
-                f16x8 v = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
+                qn[t][ds] = *reinterpret_cast<const f16x8*>(Qb + (int64_t)qrow * p.ldq + d);
+            }
+        }
+    };
+    auto finish_q = [&](const f16x8 (&qn)[2][NDS]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                f16x8 v = qn[t][ds];
                 if constexpr (FOLD) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * sl2);
                 }
                 qf[t][ds] = (ds * 32 + g * 8 < HD) ? v : zero8;       // (FOLD: element 0 of the d = HD chunk is the -reference, 0 at first)
             }
-        }
     };
     int w = lid;
     set_next(w, 0);
@@ -519,13 +591,17 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     for (int i = 0; i < NI; ++i) request_part(i, 0);
     int buf = 0;
     for (; w < nwork; w += nl) {
-        const int pair = pair_of(w / nqb), qb = w % nqb;
+        const int pair = pair_of(w / nqb), qb = qb_of(w);
         const int h = pair % p.heads, b = pair / p.heads;
         half_t* Ob = p.O + (int64_t)b * p.o_batch_stride + h * HD;
         const int q0 = qb * 256 + wave * 32;                                // this wave's queries q0 .. q0 + 31 (tiles a, b)
         const bool have = q0 < p.Tq;
+        const bool carrier = lone && qb == nqb - 1;                         // (workgroup-uniform) this block also computes query Tq - 1
+#ifdef CGPT_STAMPS
+        const unsigned long long item_begin = __builtin_amdgcn_s_memtime();
+#endif
 
-        if (w == lid) load_q(w);                                            // later items: requested in the previous item's last unit
+        if (w == lid) { f16x8 qn[2][NDS]; load_q(qn, w); finish_q(qn); }    // later items: at the end of the previous item
         f32x4 o[2][NDT];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -537,16 +613,33 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
         for (int c = 0; c < nchunks; ++c, buf ^= 1) {
             // this wave's requests for chunk c have landed; after the barrier everybody's have, and every wave is done with the
             // other buffer (chunk c-1), which the next chunk's requests may now overwrite
+            if (carrier && c == 0 && wave == 0) {
+                // the lone query's Q^T fragment for every wave, scaled like the others, its reference slot 0: the load rides on the wait
+                // for the chunk's requests, the words are visible after the chunk barrier (the previous block's readers are past theirs)
+                const half_t* qrow = p.Q + (int64_t)b * p.q_batch_stride + h * HD + (int64_t)(p.Tq - 1) * p.ldq;
+                f16x8 v = zero8;
+                if (lane < DC) v = *reinterpret_cast<const f16x8*>(qrow + lane * 8);
+                if constexpr (FOLD) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * sl2);
+                }
+                if (lane < DPAD / 8) *reinterpret_cast<f16x8*>(smem_raw + QL_OFFSET + lane * 16) = v;
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             CGPT_S2STAMP(1)                              // waiting for this wave's requests of the chunk (and the item's Q)
             __syncthreads();
             CGPT_S2STAMP(2)                              // barrier
+            if (carrier && c == 0) {
+                // this wave's partial softmax of the lone query: O^T column 0, maximum -inf, denominator 0.  (Its own LDS words, read and
+                // written in program order; behind the barrier because wave 0 may have been merging the previous block's states till then.)
+                float* st = reinterpret_cast<float*>(smem_raw + RED_OFFSET) + wave * RED_STRIDE;
+                for (int i = lane; i < RED_STRIDE; i += 64) st[i] = i == DPAD ? -1e30f : 0.f;
+            }
             if (c + 1 < nchunks) set_next(w, c + 1);
             else set_next(w + nl, 0);                      // (past the last work item: request_part does nothing)
             if (!have) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) request_part(i, buf ^ 1);
-                if (c + 1 == nchunks && w + nl < nwork) load_q(w + nl);
                 continue;
             }
             CGPT_S2STAMP(3)
@@ -585,19 +678,20 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
             read_k(kf, 0);
             qk(sc[0], kf);
             read_k(kf, 1);
-#pragma unroll
-            for (int u = 0; u < UPC; ++u) {
-                if (u >= nu) break;
+            const unsigned vlane = lds_address(Vs + (4 * g + (r15 >> 2)) * VSTR + 4 * (r15 & 3));   // this lane's corner of a unit's V rows
+            static_for_while<UPC>([&](auto uc) __attribute__((always_inline)) -> bool {
+                constexpr int u = decltype(uc)::value;
+                if (u >= nu) return false;
                 f32x4 (&s_cur)[2][2] = sc[u & 1];
                 // V fragments of unit u (two transposed 4x16 reads per d-tile)
                 f16x4 vr[NDT][2];
                 {
-                    const half_t* vbase = Vs + (u * 32 + 4 * g + (r15 >> 2)) * VSTR + 4 * (r15 & 3);
-#pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt) {
-                        vr[dt][0] = lds_read_tr16(vbase + dt * 16);
-                        vr[dt][1] = lds_read_tr16(vbase + 16 * VSTR + dt * 16);
-                    }
+                    // (one address register per chunk; unit, key half and d-tile are instruction offsets)
+                    static_for<NDT>([&](auto dtc) __attribute__((always_inline)) {
+                        constexpr int dt = decltype(dtc)::value;
+                        vr[dt][0] = lds_read_tr16_untracked<(u * 32 * VSTR + dt * 16) * 2>(vlane);
+                        vr[dt][1] = lds_read_tr16_untracked<(u * 32 * VSTR + 16 * VSTR + dt * 16) * 2>(vlane);
+                    });
                 }
                 request_unit(u, buf ^ 1);
                 // QK^T of the NEXT unit goes to the matrix pipe first ...
@@ -607,7 +701,6 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                     if (u + 1 < nu) qk(sc[(u + 1) & 1], kf);
                     if (u + 2 < UPC) read_k(kf, u + 2);
                 }
-                if (c + 1 == nchunks && u + 1 == nu && w + nl < nwork) load_q(w + nl);   // this item's last QK^T has been issued
                 // ... and this unit's softmax runs under it
                 const int kb = key0 + u * 32;
                 if (kb + 32 > p.Tk) {                                      // wave-uniform: the unit holds keys past the end
@@ -624,24 +717,17 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                 // in a wave SOME query's maximum moves in almost every unit, and rescaling 48 accumulator registers each time was a
                 // quarter of the unit's VALU work.  Now it happens when a query's scores really outgrow the reference -- normally in
                 // a block's first unit only.  The reference never exceeds the running maximum, so the largest P is >= 1.
+                // The LANE's maximum over its eight keys of the unit decides whether anything has to move ("some query's maximum exceeds
+                // the reference by 2^8" and "some lane's does" are the same statement); the maximum over a query's four lane groups --
+                // two cross-lane swaps and their shuffling per tile, a third of the softmax's plain VALU work in rounds 2-5 -- is only
+                // made where the reference really moves.
                 float mx[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float m = fmaxf(fmaxf(s_cur[t][0][0], s_cur[t][0][1]), s_cur[t][0][2]);                  // v_max3 x 3 + v_max
                     const float m2 = fmaxf(fmaxf(s_cur[t][0][3], s_cur[t][1][0]), s_cur[t][1][1]);
                     m = fmaxf(fmaxf(s_cur[t][1][2], s_cur[t][1][3]), m);
-                    m = fmaxf(m, m2);
-                    {   // the query's four lane groups: rows of 16 swapped pairwise, then the two halves of the wave.  The swap's
-                        // results go through scalars: __builtin_bit_cast applied to an ELEMENT of the returned vector reads element 0
-                        // for both (hipcc 7.2), which silently reduced the maximum over lane group 0 only.
-                        const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
-                        const unsigned a0 = a[0], a1 = a[1];
-                        m = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
-                        const auto c2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
-                        const unsigned c0 = c2[0], c1 = c2[1];
-                        m = fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
-                    }
-                    mx[t] = m;
+                    mx[t] = fmaxf(m, m2);
                 }
                 f16x8 pf[2];
                 if constexpr (FOLD) {
@@ -649,12 +735,14 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                     const bool first = c == 0 && u == 0;                   // wave-uniform: no reference yet (it is 0, o is 0)
                     if (first || __builtin_amdgcn_ballot_w64(mx[0] > RESCALE_LOG2 || mx[1] > RESCALE_LOG2) != 0) {
                         const bool nxt = u + 1 < UPC && u + 1 < nu;        // the next unit's scores exist and carry the old reference
+                        mx[0] = max_over_lane_groups(mx[0]);
+                        mx[1] = max_over_lane_groups(mx[1]);
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             const float ref_new = (float)(half_t)(m_run[t] + (first ? mx[t] : fmaxf(mx[t], 0.f)));   // what the fragment can hold
                             const float d = ref_new - m_run[t];
                             m_run[t] = ref_new;
-                            // (not in the item's last unit: no QK^T follows, and qf may already belong to the next item)
+                            // (not in the item's last unit: no QK^T follows)
                             if (g == 3 && !(c + 1 == nchunks && u + 1 == nu)) qf[t][NDS - 1][0] = (half_t)(-ref_new);
                             if (!first) {
                                 const float alpha = __builtin_amdgcn_exp2f(-d);
@@ -681,11 +769,11 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                 } else {
                     bool need = false;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) need = need || ((mx[t] - m_run[t]) * sl2 > RESCALE_LOG2);
+                    for (int t = 0; t < 2; ++t) need = need || ((mx[t] - m_run[t]) * sl2 > RESCALE_LOG2);   // (lane maxima: see above)
                     if (__builtin_amdgcn_ballot_w64(need) != 0) {          // wave-uniform
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            const float m_new = fmaxf(m_run[t], mx[t]);
+                            const float m_new = fmaxf(m_run[t], max_over_lane_groups(mx[t]));
                             const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * sl2);   // first unit: 0 (o is 0)
                             l_run[t] *= alpha;
 #pragma unroll
@@ -706,18 +794,123 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                         for (int j = 0; j < 8; ++j) pf[t][j] = (half_t)e[j];
                     }
                 }
-                // O^T += V^T P^T for both tiles
+                // O^T += V^T P^T for both tiles (the V reads are the untracked kind: one wait, tied to their registers)
+                if constexpr (NDT == 6)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0]), "+v"(vr[0][1]), "+v"(vr[1][0]), "+v"(vr[1][1]), "+v"(vr[2][0]), "+v"(vr[2][1]),
+                                 "+v"(vr[3][0]), "+v"(vr[3][1]), "+v"(vr[4][0]), "+v"(vr[4][1]), "+v"(vr[5][0]), "+v"(vr[5][1]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0]), "+v"(vr[0][1]), "+v"(vr[1][0]), "+v"(vr[1][1]), "+v"(vr[2][0]), "+v"(vr[2][1]),
+                                 "+v"(vr[3][0]), "+v"(vr[3][1]));
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     const f16x8 vf = __builtin_shufflevector(vr[dt][0], vr[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t], o[t][dt], 0, 0, 0);
                 }
-            }
+                return true;
+            });
 #pragma unroll
             for (int u = 1; u < UPC; ++u)
                 if (u >= nu) request_unit(u, buf ^ 1);    // a short last chunk: the shares of the units it does not have
+            if (carrier) {
+                // The lone query against this wave's unit of the chunk, if it has one (unit u of the pass belongs to wave u % 8; a chunk has
+                // fewer than eight).  All 16 columns of the tile hold the same query, so every lane group reads the same state words.
+                const int ul = (wave - c * (CK / 32)) & 7;
+                if (ul < nu) {
+                    float* st = reinterpret_cast<float*>(smem_raw + RED_OFFSET) + wave * RED_STRIDE;
+                    f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int ds = 0; ds < NDS; ++ds) {
+                        const f16x8 qfr = *reinterpret_cast<const f16x8*>(smem_raw + QL_OFFSET + (ds * 4 + g) * 16);
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt) {
+                            const int row = ul * 32 + kt * 16 + r15;
+                            const f16x8 kfr = *reinterpret_cast<const f16x8*>(Ks + row * KROW + k_chunk_pos<DPAD>(row, ds * 4 + g) * 8);
+                            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr, qfr, s[kt], 0, 0, 0);
+                        }
+                    }
+                    const int kb = key0 + ul * 32;
+                    float mx = -1e30f;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = FOLD ? s[kt][r] : s[kt][r] * sl2;                     // FOLD: Q was scaled when it was loaded
+                            if (kb + kt * 16 + 4 * g + r >= p.Tk) v = -1e30f;
+                            s[kt][r] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                    mx = max_over_lane_groups(mx);
+                    const float m_old = st[DPAD];
+                    const float m_new = fmaxf(m_old, mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m_old - m_new);              // first unit: 0 (the state is 0)
+                    f16x8 pfr;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+                            sum += e;
+                            pfr[kt * 4 + r] = (half_t)e;
+                        }
+                    const unsigned vaddr = lds_address(Vs + (ul * 32 + 4 * g + (r15 >> 2)) * VSTR + 4 * (r15 & 3));
+                    f32x4 ol[NDT];
+                    f16x4 vl[NDT][2];
+                    static_for<NDT>([&](auto dtc) __attribute__((always_inline)) {
+                        constexpr int dt = decltype(dtc)::value;
+                        vl[dt][0] = lds_read_tr16_untracked<dt * 16 * 2>(vaddr);
+                        vl[dt][1] = lds_read_tr16_untracked<(16 * VSTR + dt * 16) * 2>(vaddr);
+                        ol[dt] = *reinterpret_cast<const f32x4*>(st + dt * 16 + 4 * g) * alpha;
+                    });
+                    if constexpr (NDT == 6)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vl[0][0]), "+v"(vl[0][1]), "+v"(vl[1][0]), "+v"(vl[1][1]), "+v"(vl[2][0]), "+v"(vl[2][1]),
+                                     "+v"(vl[3][0]), "+v"(vl[3][1]), "+v"(vl[4][0]), "+v"(vl[4][1]), "+v"(vl[5][0]), "+v"(vl[5][1]));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vl[0][0]), "+v"(vl[0][1]), "+v"(vl[1][0]), "+v"(vl[1][1]), "+v"(vl[2][0]), "+v"(vl[2][1]),
+                                     "+v"(vl[3][0]), "+v"(vl[3][1]));
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        const f16x8 vf = __builtin_shufflevector(vl[dt][0], vl[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pfr, ol[dt], 0, 0, 0);
+                    }
+                    if (r15 == 0) {
+#pragma unroll
+                        for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<f32x4*>(st + dt * 16 + 4 * g) = ol[dt];
+                        if (g == 0) st[DPAD] = m_new;
+                    }
+                    if constexpr (!(DPAD > HD)) {                                           // no ones column in V: the row sum by VALU
+                        sum += __shfl_xor(sum, 16);
+                        sum += __shfl_xor(sum, 32);
+                        const float l_old = st[DPAD + 1];
+                        if (lane == 0) st[DPAD + 1] = l_old * alpha + sum;
+                    }
+                }
+            }
             CGPT_S2STAMP(4)                              // the chunk's units
+        }
+        if (carrier) {
+            // the eight partial softmaxes meet: wave 0 merges them and stores row Tq - 1.  (States and Q fragment are rewritten behind /
+            // in front of the next carrying block's first chunk barrier, which wave 0 reaches after this merge.)
+            __syncthreads();
+            if (wave == 0) {
+                const float* red = reinterpret_cast<const float*>(smem_raw + RED_OFFSET);
+                float mall = -1e30f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) mall = fmaxf(mall, red[k * RED_STRIDE + DPAD]);
+                float acc[2] = {0.f, 0.f}, dsum = 0.f;
+#pragma nounroll
+                for (int k = 0; k < 8; ++k) {
+                    const float wk = __builtin_amdgcn_exp2f(red[k * RED_STRIDE + DPAD] - mall);   // a wave without units: 2^-inf = 0
+                    acc[0] += wk * red[k * RED_STRIDE + lane];
+                    if (lane + 64 < DPAD) acc[1] += wk * red[k * RED_STRIDE + 64 + lane];
+                    dsum += wk * red[k * RED_STRIDE + ((DPAD > HD) ? HD : DPAD + 1)];        // the ones column of V, or the VALU row sums
+                }
+                const float inv = 1.0f / dsum;
+                half_t* orow = Ob + (int64_t)(p.Tq - 1) * p.ldo;
+                if (lane < HD) orow[lane] = (half_t)(acc[0] * inv);
+                if (lane + 64 < HD) orow[lane + 64] = (half_t)(acc[1] * inv);
+            }
         }
         if (have) {
 #pragma unroll
@@ -749,6 +942,11 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                 }
             }
         }
+        if (w + nl < nwork) { f16x8 qn[2][NDS]; load_q(qn, w + nl); CGPT_FENCE finish_q(qn); }   // (fence: all six loads, then one wait)
+#ifdef CGPT_STAMPS
+        if ((p.Tq & 255) == 1 && p.Tq > 256 && qb == (p.Tq - 1) / 256 - (lone ? 1 : 0))           // time inside the lone query's block (as a
+            ph[5] += __builtin_amdgcn_s_memtime() - item_begin;                                    // block of its own | the block that carries it)
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef CGPT_STAMPS
@@ -778,7 +976,10 @@ inline hipError_t device_cus(int& dev, int& cus) {
 
 template <int HD, int DPAD, int TKP>
 hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
-    constexpr int lds_bytes = 2 * TKP * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t);
+    // two chunk buffers + a carried lone query's eight partial softmaxes (DPAD + 4 floats each) and its Q fragment (DPAD halfs)
+    constexpr int lds_bytes = 2 * TKP * (AttnLayout<DPAD>::KROW + AttnLayout<DPAD>::VSTR) * (int)sizeof(half_t) + 8 * (DPAD + 4) * (int)sizeof(float)
+                              + DPAD * (int)sizeof(half_t);
+    static_assert(lds_bytes <= 160 * 1024, "LDS of a gfx950 CU");
     int dev = 0, num_cus = 0;
     if (hipError_t e = device_cus(dev, num_cus); e != hipSuccess) return e;
     static bool configured[kMaxDevicesA] = {false};
@@ -787,7 +988,8 @@ hipError_t launch_stream(const AttnParams& p, hipStream_t stream) {
             e != hipSuccess) return e;
         configured[dev] = true;
     }
-    const int items = p.heads * p.B * ((p.Tq + 255) / 256);
+    const bool lone = CGPT_ATT_LONE_CARRIED && (p.Tq & 255) == 1 && p.Tq > 256;          // (the kernel's own rule)
+    const int items = p.heads * p.B * (lone ? p.Tq / 256 : (p.Tq + 255) / 256);
     int grid = items < num_cus ? items : num_cus;
     if (grid >= 8) grid &= ~7;                      // a multiple of 8 enables the XCD-aware work order
     hipLaunchKernelGGL((attention_stream_kernel<HD, DPAD, TKP>), dim3(grid), dim3(512), lds_bytes, stream, p);

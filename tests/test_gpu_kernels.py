@@ -192,6 +192,45 @@ def test_streaming_attention_rising_scores_rescale_path(hd):
     report(f"streaming attention, rising scores, d{hd}", od.cpu().float().reshape(B * Tq, D), ref.reshape(B * Tq, D), 6e-3)
 
 
+@pytest.mark.parametrize("hd,Tq,Tk,B,heads", [(88, 1025, 1025, 2, 3), (88, 257, 577, 3, 2), (64, 513, 1025, 2, 2), (88, 1, 1025, 9, 2),
+                                              (64, 257, 289, 1, 1), (88, 1025, 353, 1, 2)])
+def test_streaming_attention_lone_query_is_split_by_keys(hd, Tq, Tk, B, heads):
+    """Tq = 256 k + 1 (the CLS token on a 16 n x 16 n patch grid; T = 1025 at the reference's image size, minigpt4.py:32): the last query
+    block of the streaming kernel holds one query, whose keys are split over the eight waves by 32-key unit and merged through LDS.
+    The LAST query is given a dominant key at positions that land in every wave's units, in the half-filled last unit and on both
+    sides of chunk borders (192 keys), and -- second input -- scores that rise along the keys, so that the partials of the waves carry
+    maxima dozens of powers of two apart; rows 0 .. Tq - 2 go the ordinary way and are checked with it."""
+    L = cg.lib()
+    D = heads * hd
+    scale = hd ** -0.5
+    g = torch.Generator(device="cpu").manual_seed(hd + Tq + Tk)
+    spikes = sorted({0, 31, 32, 95, 191, 192, 223, 255, 256, 287, Tk // 2, Tk - 34, Tk - 33, Tk - 2, Tk - 1})
+    for case in ("spikes", "ramp"):
+        q = torch.randn(B, Tq, D, generator=g).half()
+        k = torch.randn(B, Tk, D, generator=g).half()
+        v = torch.randn(B, Tk, D, generator=g).half()
+        if case == "spikes":
+            # sample b, head h: the lone query points at key spikes[(b * heads + h) % len]
+            for b in range(B):
+                for h in range(heads):
+                    j = spikes[(b * heads + h) % len(spikes)]
+                    q[b, Tq - 1, h * hd:(h + 1) * hd] *= 5
+                    k[b, j, h * hd:(h + 1) * hd] = q[b, Tq - 1, h * hd:(h + 1) * hd] * 0.6
+        else:
+            direction = torch.nn.functional.normalize(torch.randn(B, 1, heads, hd, generator=g), dim=-1)
+            q = (q.float().view(B, Tq, heads, hd) * 0.2 + direction * 6.0).reshape(B, Tq, D).half()
+            ramp = torch.linspace(0.0, 1.0, Tk).view(1, Tk, 1, 1)
+            k = (direction * ramp * 160.0 + torch.randn(B, Tk, heads, hd, generator=g) * 0.5).reshape(B, Tk, D).half()
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        od = torch.full((B, Tq, D), float("nan"), device=DEV, dtype=torch.float16)
+        _lib.check(L.cgpt_attention_f16(P(qd), D, P(kd), P(vd), D, P(od), D, B, heads, hd, Tq, Tk, scale, stream()))
+        torch.cuda.synchronize()
+        ref = attn_ref(q, k, v, heads, hd, scale)
+        got = od.cpu().float()
+        report(f"streaming attention, lone query ({case}) d{hd} {Tq}x{Tk}: the lone row", got[:, Tq - 1], ref[:, Tq - 1], 6e-3)
+        report(f"streaming attention, lone query ({case}) d{hd} {Tq}x{Tk}: all rows", got.reshape(B * Tq, D), ref.reshape(B * Tq, D), 6e-3)
+
+
 @pytest.mark.parametrize("rows,D", [(5, 176), (7, 128), (33, 768), (257, 1408), (3, 4096)])
 def test_layernorm_matches_torch(rows, D):
     L = cg.lib()
