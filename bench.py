@@ -11,7 +11,7 @@ estimation draws are independent, so `certify` runs them in the same classifier 
 every image -- into 255-sample classifier batches that are not aligned to image boundaries and sums all histograms of the group
 with one all-reduce (same sample indices, counts, labels and radii as K separate `certify` calls; tested).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--cpu-baseline-headline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--cpu-budget-s S] [--cpu-baseline-headline]
     (extra, NON-headline data points: --workload encode_img | rgf | minigpt4, --img-size 448, --n 1000 / --n0 K)
     environment: CGPT_BENCH_FORCE_NCCL=1 with --gpus 1 = the whole multi-rank code path over RCCL with a world of ONE rank (first contact
     with the collective on a one-GPU box); CGPT_BENCH_ONLY_TIMED=1 = profiling runs (tools/pmc_summary.py): nothing but the timed region's
@@ -27,9 +27,16 @@ Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the MLP 
 gemm9_f16_kernel<EPI_F16_GELU, true>, the two-phase quadrant kernel): achieved = 2*M*6144*1408 FLOP per launch / its mean launch duration measured with HIP
 events on the launch stream inside the timed region; `roofline.vit_gemms` lists the four ViT GEMM shapes the same way.
 `cpu_baseline` times ONE WHOLE Smooth.certify of BASELINE configs[0] (n0 = n = 10, sigma = 0.25) on the CPU oracle (oracle/, a port
-of the reference's Smooth + ViT-G forward in fp32 PyTorch) on the host cores, on rank 0 at N=1 only, and `parity` compares its
-(label, radius) and per-sample votes with the same call on the GPU; --cpu-baseline-headline adds the headline config itself on the oracle
-(~100 s: `cpu_baseline.headline_certify_s`).  `single_image_certify_ms` is the reference-shaped call.
+of the reference's Smooth + ViT-G forward in fp32 PyTorch) on the host cores of rank 0, and `parity` compares its (label, radius) and
+per-sample votes with the same call on the GPU.  At N = 1 the headline config ITSELF follows on the oracle (200 fp32 ViT-G forwards,
+~105 s on 16 threads) whenever its projected time -- 10 x the configs[0] leg just measured -- fits --cpu-budget-s (default 300; 0 =
+never, --cpu-baseline-headline = always): then `cpu_baseline.value` is that like-for-like figure (`headline_certify_s`), else the
+configs[0] leg scaled to 200 forwards.  At N > 1 rank 0 runs the configs[0] leg after the timed region while the other ranks wait at
+the final barrier, so every line carries `cpu_baseline` and `parity`.  `single_image_certify_ms` is the reference-shaped call.
+A multi-rank line explains itself: `ranks` holds, per rank, the ms of the timed region spent in its classifier passes, in the vote
+all-reduce (device and host) and in the host statistics, the classifier batches it ran (`batch_samples`, from the library's own log)
+and the batches the plan predicts (`planned_batches`); `ranks.scaling_inputs` puts the slowest rank's shares per certified image
+next to each other.
 """
 import argparse
 import json
@@ -101,13 +108,37 @@ def cpu_headline_leg(clf, x, cores):
             "headline_label_equal": int(cpu_label) == int(gpu_label), "headline_abs_dR": abs(float(cpu_radius) - float(gpu_radius))}
 
 
-def cpu_baseline_and_parity(clf, x):
+def rank_share(n_sel, n_est, r, world):
+    """Draws of one image on rank r: its slice of the n0 selection draws + its (mirrored) slice of the n estimation draws."""
+    import certifiedgpt_amd as cg
+    a, b = cg.shard_range(n_sel, r, world), cg.shard_range(n_est, r, world, mirrored=True)
+    return (a[1] - a[0]) + (b[1] - b[0])
+
+
+def planned_batches(world, lo, hi, n_sel, n_est, per_gpu, group):
+    """Samples per classifier batch, per rank, for the images [lo, hi) of a run: what `run(lo, hi)` below makes the library do.  Pure
+    host arithmetic (certifiedgpt_amd.batch_plan), so the GEMM shapes of an N-GPU run can be read -- and tested -- without N GPUs:
+    --gpus 8 --steps 20 (n0 = n = 100, 255-sample engine, up to 51 images per call) gives every rank 20 x 25 rows = [255, 245]."""
+    import certifiedgpt_amd as cg
+    plan = []
+    for r in range(world):
+        share, sizes, i = rank_share(n_sel, n_est, r, world), [], lo
+        while i < hi:
+            g = min(group, hi - i)
+            sizes += cg.batch_plan(g, share, per_gpu)       # one image: the fused pair pass cuts its rows the same way
+            i += g
+        plan.append(sizes)
+    return plan
+
+
+def cpu_baseline_and_parity(clf, x, process_group=None):
     """BASELINE configs[0] on both sides, in this run: ONE whole `Smooth.certify(x, n0=10, n=10, alpha=0.001, batch_size=10)`
     at sigma = 0.25 (a) timed on the host cores with the CPU oracle (oracle/smooth_oracle.py around the fp32 PyTorch-CPU
     ViT-G of oracle/model_oracle.py: the restatement of the reference's smoothing.py:29-56 + eva_vit.py, same weights --
     downloaded from the device -- same image, and the GPU's own noise draws, exported), and (b) run on the GPU through the
     product path.  Returns (cpu_baseline, parity): the timed CPU figure scaled to the headline unit, and the comparison of the
-    two results (label, abstain, radius, per-sample argmax agreement)."""
+    two results (label, abstain, radius, per-sample argmax agreement).  process_group: in a multi-rank run the group that holds rank 0
+    alone, so that the GPU side of this leg draws all its samples here and ends in no collective (the other ranks are waiting)."""
     import numpy as np
     import certifiedgpt_amd as cg
     from oracle import model_oracle as mo, smooth_oracle as so
@@ -118,7 +149,7 @@ def cpu_baseline_and_parity(clf, x):
     cores = host_cores()
     torch.set_num_threads(cores)
     # GPU side first (also exports the N(0,1) draws the CPU side must see)
-    smooth = cg.Smooth(clf, NUM_CLASSES, sigma, seed=seed)
+    smooth = cg.Smooth(clf, NUM_CLASSES, sigma, seed=seed, process_group=process_group, force_collective=False)
     gpu_label, gpu_radius = smooth.certify(x, n0, n, alpha, 10)
     gpu_logits = clf.forward_logits(x, 0, n0 + n, sigma, seed).cpu()
     draws = cg.noise_batch(torch.zeros_like(x), 0, n0 + n, 1.0, seed).cpu().numpy()
@@ -182,6 +213,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # the CPU leg on the headline config itself (n0 = n = 100, sigma = 0.5: ~100 s of host time) beside the default configs[0] leg
     ap.add_argument("--cpu-baseline-headline", action="store_true")
+    # ... which also runs by default at --gpus 1 when its projected time (10 x the configs[0] leg) fits this many seconds; 0 = never
+    ap.add_argument("--cpu-budget-s", type=float, default=300.0)
     # extra data points (NOT the headline line): BASELINE configs[2] without the Vicuna decode, and the reference's own 448^2 size
     ap.add_argument("--workload", choices=["vit_head", "encode_img", "rgf", "minigpt4"], default="vit_head")
     ap.add_argument("--img-size", type=int, default=224)
@@ -233,6 +266,9 @@ def main():
         assert dist.get_world_size() == args.gpus and dist.get_backend() == backend
     else:
         torch.cuda.set_device(local)
+    # a group that holds rank 0 alone (every rank must take part in making it): rank 0's CPU / parity leg draws all of its samples
+    # on its own GPU and ends in no collective while the other ranks wait at the final barrier
+    solo = dist.new_group(ranks=[0]) if world > 1 else None
 
     import certifiedgpt_amd as cg
     if os.environ.get("CGPT_GEMM_KERNEL"):          # A/B measurements only; default = the library's own choice
@@ -249,10 +285,7 @@ def main():
         _lib.check(cg.lib().cgpt_set_option(b"sync_batches", 1))
     dev = torch.device("cuda", local)
     # certify runs its n0 + n draws as ONE fused pass; the largest per-rank share of it is one batch
-    def _share(r):
-        a, b = cg.shard_range(n_sel, r, world), cg.shard_range(n_est, r, world, mirrored=True)
-        return (a[1] - a[0]) + (b[1] - b[0])
-    share = max(_share(r) for r in range(world))                      # draws of one image per rank: 25 at 8 GPUs (13 + 12)
+    share = max(rank_share(n_sel, n_est, r, world) for r in range(world))   # draws of one image per rank: 25 at 8 GPUs (13 + 12)
     # Classifier batch capacity.  Smooth.certify_many cuts the (image, sample) rows of a group of images into batches of this
     # size, not aligned to image boundaries, so it is chosen for the GEMMs: 255 samples x 257 tokens = 65 535 rows = 256 tile
     # rows of 256 -> every GEMM's tile count is a multiple of the 256 CUs (200 samples: 201 tile rows, 96 % tile efficiency).
@@ -342,16 +375,56 @@ def main():
         # and how many ranks the communicator really summed over (a SUM of ones through the same backend as the vote counts)
         tm = smooth.timing()
         smooth.collect_timing(False)
-        mine = torch.tensor([1e3 * t_rank, tm["compute_ms"], tm["allreduce_ms"], tm["allreduce_host_ms"], float(tm["calls"])],
+        # the classifier batches this rank ran in the timed region (library log since profile(True)), as [size, count] runs
+        ran = clf.profile_batches()
+        runs = []
+        for v in ran:
+            if runs and runs[-1][0] == v:
+                runs[-1][1] += 1
+            else:
+                runs.append([v, 1])
+        runs = runs[:16] + [[-1, 0]] * (16 - min(16, len(runs)))          # fixed width for the gather; -1 pads
+        mine = torch.tensor([1e3 * t_rank, tm["compute_ms"], tm["allreduce_ms"], tm["allreduce_host_ms"], float(tm["calls"]),
+                             tm["stats_host_ms"], float(len(ran))] + [float(v) for pair in runs for v in pair],
                             device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         ones = torch.ones(1, device=dev, dtype=torch.int64)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         rows = [[float(v) for v in r.tolist()] for r in allr]
+        plan = planned_batches(world, args.warmup, args.warmup + args.steps, n_sel, n_est, per_gpu, group) if not (rgf or gen) else None
+
+        def runs_of(r):
+            return [[int(r[7 + 2 * k]), int(r[8 + 2 * k])] for k in range(16) if r[7 + 2 * k] >= 0]
+
+        def as_runs(sizes):
+            out = []
+            for v in sizes:
+                if out and out[-1][0] == v:
+                    out[-1][1] += 1
+                else:
+                    out.append([v, 1])
+            return out
+        slow = max(range(world), key=lambda i: rows[i][1])                # the rank with the longest classifier passes
         ranks_report = {"summed_ranks": int(ones.item()),
                         "per_rank_ms": [{"rank": i, "total": r[0], "classifier_passes": r[1], "all_reduce_device": r[2],
-                                         "all_reduce_host": r[3], "sample_noise_calls": int(r[4])} for i, r in enumerate(rows)],
+                                         "all_reduce_host": r[3], "host_statistics": r[5], "sample_noise_calls": int(r[4]),
+                                         "classifier_batches": int(r[6]), "batch_samples": runs_of(r),
+                                         "planned_batches": as_runs(plan[i])[:16] if plan is not None else None}
+                                        for i, r in enumerate(rows)],
+                        "batches_as_planned": (all(runs_of(r) == as_runs(plan[i])[:16] for i, r in enumerate(rows))
+                                               if plan is not None else None),
+                        # what a scaling number is made of: the slowest rank's ms per certified image in its own classifier passes, in the
+                        # all-reduce on the device (includes waiting for the slowest rank), in the host statistics, and the rest of the
+                        # step (launch gaps, the device->host copies, Python); speed-up over one GPU = that run's ms_per_step / this total
+                        "scaling_inputs": {"slowest_rank": slow,
+                                           "classifier_ms_per_image": rows[slow][1] / args.steps,
+                                           "all_reduce_device_ms_per_image": rows[slow][2] / args.steps,
+                                           "host_statistics_ms_per_image": rows[slow][5] / args.steps,
+                                           "other_ms_per_image": (1e3 * elapsed - rows[slow][1] - rows[slow][2] - rows[slow][5]) / args.steps,
+                                           "ms_per_step": 1e3 * elapsed / args.steps,
+                                           "note": "projected ceilings on one GPU (DESIGN.md section 6, profiles/r04/shard_bench.txt): certify_many "
+                                                   "8.0x at 8 GPUs (12.7 ms per image per rank), the reference-shaped per-image call 5.9x (17.65 ms)"},
                         "rank_total_ms_max": max(r[0] for r in rows), "rank_total_ms_min": min(r[0] for r in rows),
                         "classifier_ms_max": max(r[1] for r in rows), "classifier_ms_min": min(r[1] for r in rows),
                         "all_reduce_device_ms_max": max(r[2] for r in rows),
@@ -598,16 +671,29 @@ def main():
             line.pop("vit_tflops_end_to_end", None)
             line["roofline"]["traffic"] = None
             line["roofline"]["flop_per_launch"] = fc1_flops / max(fc1_n, 1)
-        if world == 1 and not args.no_cpu_baseline and headline:
+        if not args.no_cpu_baseline and headline:
             try:
-                line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(clf, images[0])
-                line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
-                if args.cpu_baseline_headline:
-                    line["cpu_baseline"].update(cpu_headline_leg(clf, images[0], line["cpu_baseline"]["cores"]))
-                    line["gpu_over_cpu_headline"] = value / line["cpu_baseline"]["headline_images_per_s"]
+                cb, line["parity"] = cpu_baseline_and_parity(clf, images[0], process_group=solo)
+                line["cpu_baseline"] = cb
+                # the like-for-like leg: the headline config itself on the oracle, when it fits the budget (single rank only: at N > 1
+                # the other ranks are waiting at the barrier below)
+                projected = cb["config0_certify_s"] * (N0 + N) / 20.0
+                want = args.cpu_baseline_headline or (world == 1 and 0 < projected <= args.cpu_budget_s)
+                cb["headline_leg"] = ("ran" if want else "skipped") + (": projected %.0f s (10 x the configs[0] leg) against --cpu-budget-s %.0f"
+                                                                      % (projected, args.cpu_budget_s)) + \
+                                     ("" if world == 1 else "; multi-rank run: configs[0] leg only")
+                if want:
+                    cb.update(cpu_headline_leg(clf, images[0], cb["cores"]))
+                    cb["value_config0_scaled"] = cb["value"]
+                    cb["value"] = cb["headline_images_per_s"]
+                    cb["sample"] = cb["headline_sample"] + " (like for like with `value`); config0_* = the BASELINE configs[0] leg: " + cb["sample"]
+                    line["gpu_over_cpu_headline"] = value / cb["headline_images_per_s"]
+                line["gpu_over_cpu"] = value / cb["value"]
             except Exception as e:  # the CPU leg must never void the GPU measurement
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
+    if collective:
+        barrier()                                    # ranks > 0 wait here while rank 0 runs the CPU leg
     clf.close()
     if collective:
         dist.destroy_process_group()

@@ -70,6 +70,7 @@ SIGNATURES = {
     "cgpt_profile_enable": (_I32, [_P, _I32]),
     "cgpt_profile_read": (_I32, [_P, _I32, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I64)]),
     "cgpt_profile_clock": (_I32, [_P, _I32, C.POINTER(_D)]),
+    "cgpt_profile_batches": (_I32, [_P, C.POINTER(_I32), _I64, C.POINTER(_I64)]),
     "cgpt_gemm_f16": (_I32, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "cgpt_linear_f16": (_I32, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _I64, _I64, _I32, _P]),
     "cgpt_attention_f16": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _F, _P]),

@@ -203,6 +203,14 @@ class HipClassifier:
         _lib.check(self._L.cgpt_profile_read(self._h, kind, C.byref(ms), C.byref(fl), C.byref(n)))
         return ms.value, fl.value, n.value
 
+    def profile_batches(self):
+        """Samples of every classifier forward since profile(True), in order (cgpt_profile_batches): how the sample ranges were cut."""
+        n = C.c_int64()
+        _lib.check(self._L.cgpt_profile_batches(self._h, None, 0, C.byref(n)))
+        buf = (C.c_int32 * max(1, n.value))()
+        _lib.check(self._L.cgpt_profile_batches(self._h, buf, n.value, C.byref(n)))
+        return [int(v) for v in buf[:n.value]]
+
     def profile_clock(self, kind=0):
         """GHz the profiled GEMMs of `kind` ran at (in-kernel s_memtime / s_memrealtime of every workgroup; cgpt_profile_clock).
         Read before profile_read(0), which resets the sums.  0.0 when nothing was profiled."""

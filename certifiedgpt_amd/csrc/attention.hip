@@ -697,8 +697,11 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                 // QK^T of the NEXT unit goes to the matrix pipe first ...
                 // (unconditionally inside the chunk: a conditional fragment read makes the compiler split the fp16 vectors into
                 // halves and re-pack them with v_perm in front of every MFMA; units past the end read valid LDS and are never used)
+                // (the products too: skipping them for a unit past the end leaves a join at which hipcc, not knowing what is in flight on
+                // the other path, waits for ALL LDS reads -- the uncounted V reads included -- after the first K fragment read; a short
+                // last chunk pays 12 MFMAs on valid, unused LDS contents once per block)
                 if (u + 1 < UPC) {
-                    if (u + 1 < nu) qk(sc[(u + 1) & 1], kf);
+                    qk(sc[(u + 1) & 1], kf);
                     if (u + 2 < UPC) read_k(kf, u + 2);
                 }
                 // ... and this unit's softmax runs under it

@@ -372,13 +372,17 @@ __global__ __launch_bounds__(512, 2) void gemm9_f16_kernel(GemmParams p) {
         else tile_body(IntTag9<4>{}, tm, ncol0);
     }
 #ifdef CGPT_STAMPS
-    if (p.dbg && lane == 0) {
+    // Three tables of FIXED capacity (256 workgroups: one per CU; the grid varies with cgpt_set_option("gemm_grid") and with shapes of
+    // fewer tiles than CUs, the readers -- tools/gemm_wg_balance.py, scratch stamp scripts -- index by this capacity and size their
+    // buffer as 256 * 8 * 12 + 512 words): [wg][wave][4], then [wg][wave][8] phase stamps, then [wg][begin, end].
+    constexpr size_t STAMP_WGS = 256;
+    if (p.dbg && lane == 0 && blockIdx.x < STAMP_WGS) {
         unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
         d[0] = __builtin_amdgcn_s_memtime() - st_begin; d[1] = st_first; d[2] = st_loop; d[3] = st_epi;
-        unsigned long long* e = p.dbg + (size_t)gridDim.x * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8;   // second table: phase stamps
+        unsigned long long* e = p.dbg + STAMP_WGS * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8;   // second table: phase stamps
         for (int k = 0; k < 8; ++k) e[k] = ph9[k];
         if (wave == 0) {   // third table: [workgroup][begin, end] in 100-MHz real-time ticks (how evenly the workgroups finish)
-            unsigned long long* r = p.dbg + (size_t)gridDim.x * 8 * 12 + (size_t)blockIdx.x * 2;
+            unsigned long long* r = p.dbg + STAMP_WGS * 8 * 12 + (size_t)blockIdx.x * 2;
             r[0] = clk_r0; r[1] = __builtin_amdgcn_s_memrealtime();
         }
     }

@@ -93,6 +93,7 @@ struct cgpt_model {
     std::vector<ProfEvent> events;
     std::vector<hipEvent_t> event_pool;      // timing-only events (hipEventDisableSystemFence), reused across profile_read(0) drains
     unsigned long long* clk_dev = nullptr;   // [8][2]: per GEMM kind, shader cycles and 100-MHz ticks summed over workgroups (cgpt_profile_clock)
+    std::vector<int32_t> batch_log;          // samples of every classifier forward while profiling is on (cgpt_profile_batches)
 };
 
 namespace {
@@ -339,6 +340,7 @@ cgpt_status forward(cgpt_model* m, const float* src, bool noise, int64_t first_s
     const cgpt_config& c = m->cfg;
     const int D = m->D, Dk = m->Dk, T = m->T, P = m->P, M = nb * T;
     m->pending_delta = false;
+    if (m->profile && m->batch_log.size() < (1u << 20)) m->batch_log.push_back(nb);
     // K1 + im2col: smoothing.py:95-96 fused into the patch-embed operand (eva_vit.py:202,209)
     if (noise) HIPCHK(launch_noise_im2col(src, c.img_size, c.patch_size, first_sample, na, first_b, nb, sigma, seed, m->Apatch, m->Kpatch_p, st, per, img_stride, row0));
     else HIPCHK(launch_im2col(src, c.img_size, c.patch_size, nb, m->Apatch, m->Kpatch_p, st));
@@ -829,7 +831,17 @@ cgpt_status cgpt_debug_set_gemm_stamps(void* dev_buf) { g_gemm_dbg = (unsigned l
 
 cgpt_status cgpt_profile_enable(cgpt_handle h, int32_t on) {
     if (!h) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_profile_enable: null handle");
+    if (on && !h->profile) h->batch_log.clear();
     h->profile = on != 0;
+    return CGPT_OK;
+}
+
+cgpt_status cgpt_profile_batches(cgpt_handle h, int32_t* samples_out, int64_t capacity, int64_t* count_out) {
+    if (!h || !count_out || capacity < 0 || (capacity > 0 && !samples_out))
+        return cgpt_fail(CGPT_ERR_INVALID, "cgpt_profile_batches: null argument");
+    const int64_t n = (int64_t)h->batch_log.size();
+    *count_out = n;
+    for (int64_t i = 0; i < n && i < capacity; ++i) samples_out[i] = h->batch_log[i];
     return CGPT_OK;
 }
 

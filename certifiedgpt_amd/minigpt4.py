@@ -346,11 +346,15 @@ class MiniGPT4Classifier:
 
     def hf_generate_kwargs(self):
         """`generate_kwargs` as handed to the installed `generate`: the reference's `min_length` travels as `min_new_tokens`, which
-        means "generated tokens" in every transformers version (and takes precedence over min_length where both exist)."""
+        means "generated tokens" in every transformers version (and takes precedence over min_length where both exist), and
+        `min_length` itself is handed over as an explicit 0."""
         kw = dict(self.generate_kwargs)
         ml = kw.pop("min_length", None)
         if ml and "min_new_tokens" not in kw:
             kw["min_new_tokens"] = int(ml)
+        # never SILENT on min_length: where the call says nothing `generate` applies the checkpoint's own generation_config.min_length,
+        # which the greedy loop (min_new_tokens() above) would not see -- the two decode paths of one classifier would then differ
+        kw["min_length"] = 0
         return kw
 
     def greedy_tokens(self, embs, return_logits=False):

@@ -40,6 +40,17 @@ def shard_range(num: int, rank: int, world: int, mirrored: bool = False):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def batch_plan(num_images: int, rows_per_image: int, max_batch: int):
+    """Samples per classifier batch, in order, when `cgpt_sample_counts_images` runs `rows_per_image` draws of each of `num_images`
+    images on an engine of capacity `max_batch`: the rows of all images form one image-major sequence that is cut into windows of
+    `max_batch` rows, not aligned to image boundaries (csrc/model.hip).  With one image this is also `_sample_noise`'s own loop
+    (smoothing.py:91-98: `this_batch_size = min(batch_size, num)`).  Pure host arithmetic: what `HipClassifier.profile_batches()`
+    must report, and what a multi-GPU run's GEMM shapes will be before any GPU is touched (20 images x 25 draws on a 255-sample
+    engine -> [255, 245])."""
+    total = int(num_images) * int(rows_per_image)
+    return [min(int(max_batch), total - r0) for r0 in range(0, total, int(max_batch))]
+
+
 class Smooth(object):
     """A smoothed classifier g (smoothing.py:13)."""
 
@@ -84,7 +95,7 @@ class Smooth(object):
         """Start (or stop) recording, for every `_sample_noise`-type call, HIP events around this rank's classifier pass and around
         the all-reduce, plus the host time spent inside `dist.all_reduce`.  Nothing is synchronised while recording; `timing()`
         resolves the events.  Used by bench.py so that a multi-GPU line explains itself (compute vs collective per rank)."""
-        self._timing = {"compute": [], "allreduce": [], "allreduce_host_s": 0.0, "calls": 0} if on else None
+        self._timing = {"compute": [], "allreduce": [], "allreduce_host_s": 0.0, "stats_host_s": 0.0, "calls": 0} if on else None
 
     def timing(self):
         """-> dict(compute_ms, allreduce_ms, allreduce_host_ms, calls) of this rank since collect_timing(True) (synchronises)."""
@@ -95,7 +106,7 @@ class Smooth(object):
             torch.cuda.synchronize()
         ms = lambda pairs: float(sum(a.elapsed_time(b) for a, b in pairs))
         return {"compute_ms": ms(t["compute"]), "allreduce_ms": ms(t["allreduce"]), "allreduce_host_ms": 1e3 * t["allreduce_host_s"],
-                "calls": t["calls"]}
+                "stats_host_ms": 1e3 * t["stats_host_s"], "calls": t["calls"]}
 
     def _timed_compute(self, fn):
         t = self._timing
@@ -194,7 +205,16 @@ class Smooth(object):
                                                                           n0 + n, float(self.sigma), self.seed))
         if self._reduces(world):
             self._all_reduce(counts)
-        return [self._certifiable(r) for r in self.certify_many_from_counts(counts.cpu().numpy(), n, alpha)]
+        if self._timing is None:
+            return [self._certifiable(r) for r in self.certify_many_from_counts(counts.cpu().numpy(), n, alpha)]
+        # measurement: the host's share of a group of images -- the one device->host copy of the [G,2,K] table (which waits for the
+        # device) is NOT in it, the float64 statistics (Clopper-Pearson bound, Phi^-1) of the G images are
+        import time
+        table = counts.cpu().numpy()
+        h0 = time.perf_counter()
+        out = [self._certifiable(r) for r in self.certify_many_from_counts(table, n, alpha)]
+        self._timing["stats_host_s"] += time.perf_counter() - h0
+        return out
 
     def certify_images(self, xs, n0: int, n: int, alpha: float, batch_size: int):
         """`certify` for a stack of images xs[G,3,H,W] (or a sequence of G image tensors), IMAGE-sharded (SURVEY.md 8(e), the zero-communication throughput mode;

@@ -227,6 +227,11 @@ cgpt_status cgpt_profile_read(cgpt_handle h, int32_t kind, double* total_ms, dou
  * give-back shows up here; bench.py prints that share as roofline.implied_mfma_busy_frac.  (roofline.pmc.mfma_busy_frac and .clock_ghz
  * come from a separate rocprofv3 --pmc run, which holds other clocks: never multiply numbers of the two runs.) */
 cgpt_status cgpt_profile_clock(cgpt_handle h, int32_t kind, double* clock_ghz);
+/* The classifier batches the handle ran since profiling was last switched on, in order: samples (rows of smoothing.py:93-97's `batch`)
+ * of every base-classifier forward, i.e. how cgpt_sample_counts* cut their sample ranges (smoothing.py:91-98: `this_batch_size`).
+ * *count_out = number of forwards; the first min(count, capacity) sizes are written to samples_out (capacity 0: count only).  Host
+ * bookkeeping only, nothing is synchronised.  bench.py prints it per rank, so that a multi-GPU line shows the GEMM shapes it ran. */
+cgpt_status cgpt_profile_batches(cgpt_handle h, int32_t* samples_out, int64_t capacity, int64_t* count_out);
 
 /* Process-wide SPEED knobs.  No option changes a result: every accepted value gives bit-identical outputs (tested).
  * THREADING OF THE LIBRARY (not only of a handle): these options AND the per-device first-launch caches of the kernel launchers (LDS

@@ -351,3 +351,26 @@ def test_image_sharded_calls_accept_a_list_and_touch_only_the_ranks_own_images()
         assert p.exitcode == 0
     for rank, out, pred, cursor in got:
         assert out == want and pred == want_pred and cursor == ref._next_sample, (rank, out, want)
+
+
+def test_eight_gpu_batch_plan_is_the_shapes_of_design_section_6():
+    """VERDICT r5 item 5a, the part that needs no GPU: the per-rank classifier batches of the driver's 8-GPU command
+    (`bench.py --gpus 8 --steps 20 --warmup 5`, n0 = n = 100, 255-sample engines, up to 51 images per certify_many call) are
+    20 images x 25 draws = 500 rows -> [255, 245] on EVERY rank (13 + 12 and 12 + 13 draws: the mirrored remainders), the warm-up's
+    5 images -> [125]; N = 1 runs 15 full 255-sample batches + 175.  bench.py prints the same plan beside the batches the library
+    logged (`ranks.per_rank_ms[*].planned_batches` / `batch_samples`); tests/test_gpu_distributed.py checks on the GPU, at four
+    ranks, that the log equals the plan.  (smoothing.py:91-98 is the loop whose batch sizes these are.)"""
+    import bench
+    import certifiedgpt_amd as cg
+    assert [bench.rank_share(100, 100, r, 8) for r in range(8)] == [25] * 8
+    assert bench.planned_batches(8, 5, 25, 100, 100, 255, 51) == [[255, 245]] * 8
+    assert bench.planned_batches(8, 0, 5, 100, 100, 255, 51) == [[125]] * 8
+    one = bench.planned_batches(1, 5, 25, 100, 100, 255, 51)[0]
+    assert one == [255] * 15 + [175] and sum(one) == 20 * 200
+    # 2 and 4 GPUs: 100 / 50 draws per image and rank
+    assert bench.planned_batches(2, 5, 25, 100, 100, 255, 51) == [[255] * 7 + [215]] * 2
+    assert bench.planned_batches(4, 5, 25, 100, 100, 255, 51) == [[255] * 3 + [235]] * 4
+    # groups of 51 images are separate calls: 60 images on one GPU = 51 + 9
+    assert bench.planned_batches(1, 0, 60, 100, 100, 255, 51)[0] == [255] * 40 + [255] * 7 + [15]
+    # ragged shares (N = 1000 over 8 GPUs is 125 + 13/12 of n0 = 100) and the one-image call
+    assert cg.batch_plan(1, 138, 200) == [138] and cg.batch_plan(3, 138, 200) == [200, 200, 14] and cg.batch_plan(0, 5, 8) == []

@@ -209,7 +209,7 @@ def test_bench_ranks_block_over_nccl_on_one_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                        "--cpu-budget-s", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["collective_backend"] == "nccl" and line["rccl_ranks"] == 1
@@ -218,6 +218,21 @@ def test_bench_ranks_block_over_nccl_on_one_gpu():
     assert rk["per_rank_ms"][0]["sample_noise_calls"] >= 1 and rk["per_rank_ms"][0]["all_reduce_host"] > 0
     assert line["image_sharded"]["equals_sample_sharded"] is True
     assert line["value"] > 0
+    # a line of the collective code path carries the CPU leg and the parity block too (configs[0] on the oracle and
+    # on the GPU; --cpu-budget-s 0 keeps the 105-s headline leg out of the test suite and the line says so)
+    _assert_cpu_leg(line, headline_leg=False)
+    # ... and shows the classifier batches it ran, equal to the plan (2 images x 200 draws on a 255-sample engine)
+    assert rk["batches_as_planned"] is True and rk["per_rank_ms"][0]["batch_samples"] == [[255, 1], [145, 1]]
+    assert rk["per_rank_ms"][0]["host_statistics"] > 0 and rk["scaling_inputs"]["classifier_ms_per_image"] > 0
+
+
+def _assert_cpu_leg(line, headline_leg):
+    cb, par = line["cpu_baseline"], line["parity"]
+    assert "error" not in cb, cb
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["config0_certify_s"] > 0
+    assert cb["headline_leg"].startswith("ran" if headline_leg else "skipped")
+    assert par["label_equal"] is True and par["abs_dR"] <= 1e-3 and par["argmax_agreement"] == "20/20"   # the north star's tolerance on R
+    assert line["gpu_over_cpu"] > 1
 
 
 def test_bench_self_launches_its_ranks():
@@ -229,11 +244,14 @@ def test_bench_self_launches_its_ranks():
     root = os.path.dirname(HERE)
     env = dict(os.environ, CGPT_BENCH_ONE_GPU_REHEARSAL="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["collective_backend"] == "gloo" and line["rccl_ranks"] == 0
+    # rank 0 ran the configs[0] CPU + parity leg while rank 1 waited at the final barrier (never the 105-s headline leg at N > 1)
+    _assert_cpu_leg(line, headline_leg=False)
+    assert "multi-rank" in line["cpu_baseline"]["headline_leg"]
     assert line["value"] > 0 and line["single_image_certify_ms"] > 0
     # a multi-rank line explains itself: per-rank classifier / all-reduce / total times and the number of ranks the collective summed over
     rk = line["ranks"]
@@ -242,6 +260,9 @@ def test_bench_self_launches_its_ranks():
         assert r["classifier_passes"] > 0 and r["all_reduce_device"] >= 0 and r["sample_noise_calls"] >= 1
         assert r["total"] >= r["classifier_passes"] * 0.5
     assert rk["rank_total_ms_max"] >= rk["rank_total_ms_min"] > 0
+    # 3 images x 100 draws per rank on a 255-sample engine: the library's own log says [255, 45] on both ranks, as planned
+    assert rk["batches_as_planned"] is True
+    assert all(r["batch_samples"] == [[255, 1], [45, 1]] == r["planned_batches"] for r in rk["per_rank_ms"])
     # both partitions of SURVEY.md 8(e) in one line: the image-sharded pass certifies the same images to the same (label, radius) list
     im = line["image_sharded"]
     assert im["equals_sample_sharded"] is True and im["value"] > 0 and im["images_per_rank_max"] == 2
@@ -254,6 +275,36 @@ def test_bench_self_launches_its_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_four_rank_rehearsal_runs_the_planned_batches():
+    """First-contact checklist for the 8-GPU node.  The GEMM shapes of an N-rank run are decided by how every
+    rank's rows are cut into classifier batches; `bench.planned_batches` is that rule as host arithmetic (tests/test_distributed_cpu.py
+    evaluates it at world 8: --gpus 8 --steps 20 --warmup 5 -> [255, 245] on every rank), and here a FOUR-rank
+    rehearsal on this one GPU (gloo, all ranks on cuda:0) checks that what the library really ran -- its own batch log, per rank -- is
+    the plan: 8 images x 50 draws per rank = 400 rows -> [255, 145].  Four ranks, not eight: the GPU boxes of this pool kill a run
+    with more than six processes on the card (pytest + 4 ranks = 5)."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, root)
+    import bench
+    env = dict(os.environ, CGPT_BENCH_ONE_GPU_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "8", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rk = line["ranks"]
+    assert line["n_gpus"] == 4 and rk["summed_ranks"] == 4 and rk["batches_as_planned"] is True
+    plan = bench.planned_batches(4, 0, 8, 100, 100, 255, 51)
+    assert plan == [[255, 145]] * 4
+    for r in rk["per_rank_ms"]:
+        assert r["batch_samples"] == [[255, 1], [145, 1]] and r["classifier_batches"] == 2
+    si = rk["scaling_inputs"]
+    assert si["classifier_ms_per_image"] > 0 and si["host_statistics_ms_per_image"] > 0 and si["ms_per_step"] > 0
+    assert line["image_sharded"]["equals_sample_sharded"] is True
 
 
 def test_c_level_allreduce_counts_single_rank_communicator():

@@ -230,7 +230,7 @@ def test_first_token_is_never_eos_on_either_decode_path_whatever_transformers_is
     llm, emb, embs = _eos_first_llm()
     clf = _classifier(llm=llm)
     kw = clf.hf_generate_kwargs()
-    assert kw.get("min_new_tokens") == 1 and "min_length" not in kw and clf.min_new_tokens() == 1
+    assert kw.get("min_new_tokens") == 1 and kw["min_length"] == 0 and clf.min_new_tokens() == 1
     with torch.no_grad():
         hf = llm.generate(inputs_embeds=embs, attention_mask=torch.ones(embs.shape[:2], dtype=torch.int), max_new_tokens=6, **kw)
         loop = clf.greedy_tokens(embs)
@@ -242,6 +242,25 @@ def test_first_token_is_never_eos_on_either_decode_path_whatever_transformers_is
     assert clf0.min_new_tokens() == 0 and "min_new_tokens" not in clf0.hf_generate_kwargs()
     with torch.no_grad():
         assert bool((clf0.greedy_tokens(embs)[:, 0] == EOS).all())
+
+
+def test_checkpoint_min_length_cannot_split_the_decode_paths():
+    """a checkpoint whose generation_config.json carries min_length > 0.  The call used to be SILENT on min_length (it
+    travels as min_new_tokens), so `generate` applied the checkpoint's value while the greedy loop did not know it.  Now the HF call
+    carries an explicit min_length = 0 beside min_new_tokens: both paths suppress EOS for exactly min_new_tokens() generated tokens,
+    with the reference's min_length = 1 and with min_length = 0."""
+    from toy_llm import EOS
+    llm, emb, embs = _eos_first_llm()
+    llm.generation_config.min_length = 3
+    for gk, first_is_eos in (({}, False), ({"min_length": 0}, True)):
+        clf = _classifier(llm=llm, generate_kwargs=gk)
+        kw = clf.hf_generate_kwargs()
+        assert kw["min_length"] == 0 and clf._greedy_defaults() is True
+        with torch.no_grad():
+            hf = llm.generate(inputs_embeds=embs, attention_mask=torch.ones(embs.shape[:2], dtype=torch.int), max_new_tokens=6, **kw)
+            loop = clf.greedy_tokens(embs)
+        assert bool((hf[:, 0] == EOS).all()) == first_is_eos and bool((loop[:, 0] == EOS).all()) == first_is_eos
+        assert clf._decode_outputs(loop) == clf._decode_outputs(hf)
 
 
 def test_checkpoint_generation_config_sends_the_call_down_the_hf_path():

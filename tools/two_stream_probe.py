@@ -4,7 +4,15 @@ streams (two handles, two host threads); the persistent 256 x 256 GEMM is told t
 other stream's LayerNorm / attention workgroups find a place while a GEMM runs (a GEMM workgroup fills its CU's register file: nothing
 co-resides with it).  Same images, same sample indices, same results in every configuration (checked); certified images / s.
 
-    python tools/two_stream_probe.py [images_per_stream=51] [rounds=2]"""
+    python tools/two_stream_probe.py [images_per_stream=51] [rounds=2]
+NOTE: this probe drives two handles on the SAME device from two host threads and flips the process-global "gemm_grid"
+option between runs.  include/cgpt.h supports one thread per handle on DIFFERENT devices only; the probe is safe because (a) a
+complete certify_many has run from the main thread (`one_stream()`, the first warm-up call) before any worker thread starts, so every
+per-DEVICE first-launch cache of the launchers (LDS attribute, CU count) is already set and only read afterwards, (b) a handle owns its
+workspace and weights (nothing is
+shared between handles but read-only globals), and (c) the option is set only between runs, with both streams synchronised.  Its
+conclusion ("overlap across batches: closed", profiles/r05/two_stream_probe.txt) rests on that warm-up; it is not a supported deployment.
+"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
