@@ -282,7 +282,9 @@ def main():
         _lib.check(cg.lib().cgpt_set_option(b"gemm_ablate", int(os.environ["CGPT_GEMM_ABLATE"])))
     if os.environ.get("CGPT_BENCH_ONLY_TIMED", "") not in ("", "0"):   # profiling runs: bounded number of dispatches in flight
         from certifiedgpt_amd import _lib
-        _lib.check(cg.lib().cgpt_set_option(b"sync_batches", 1))
+        # (CGPT_BENCH_NO_SYNC=1 / CGPT_BENCH_TRACE_BATCHES=1: the one diagnostic run of profiles/r06/pmc_sigsegv.txt)
+        _lib.check(cg.lib().cgpt_set_option(b"sync_batches", 0 if os.environ.get("CGPT_BENCH_NO_SYNC") else 1))
+        _lib.check(cg.lib().cgpt_set_option(b"trace_batches", 1 if os.environ.get("CGPT_BENCH_TRACE_BATCHES") else 0))
     dev = torch.device("cuda", local)
     # certify runs its n0 + n draws as ONE fused pass; the largest per-rank share of it is one batch
     share = max(rank_share(n_sel, n_est, r, world) for r in range(world))   # draws of one image per rank: 25 at 8 GPUs (13 + 12)

@@ -558,7 +558,14 @@ static cgpt_status check_call(cgpt_handle h, const void* p1, const void* p2, int
 // a profiler that keeps one record per dispatch in flight (rocprofv3 --pmc) runs out of room when one call enqueues tens of thousands of
 // dispatches without a host synchronisation (40 batches x ~400 kernels at 51 images per cgpt_sample_counts_images call).  Never changes a result.
 static int g_sync_batches = 0;
-#define CGPT_BATCH_DONE(st) do { if (g_sync_batches) HIPCHK(hipStreamSynchronize(st)); } while (0)
+// cgpt_set_option("trace_batches", 1): one stderr line per classifier batch ENQUEUED by the sample_counts* entry points (host side, in
+// front of the optional synchronisation): tells a log how far a call got (profiles/r06/pmc_sigsegv.txt).  Measurement aid.
+static int g_trace_batches = 0;
+static long g_batches_enqueued = 0;
+#define CGPT_BATCH_DONE(st) do { \
+        ++g_batches_enqueued; \
+        if (g_trace_batches) fprintf(stderr, "libcgpt: classifier batch %ld enqueued%s\n", g_batches_enqueued, g_sync_batches ? " (synchronising)" : ""); \
+        if (g_sync_batches) HIPCHK(hipStreamSynchronize(st)); } while (0)
 
 cgpt_status cgpt_sample_counts(cgpt_handle h, const float* x_dev, int64_t first_sample, int64_t num, int64_t batch_size,
                                float sigma, uint64_t noise_seed, int64_t* counts_dev, void* stream) {
@@ -813,6 +820,7 @@ cgpt_status cgpt_set_option(const char* key, int32_t value) {
         return CGPT_OK;
     }
     if (k == "sync_batches") { g_sync_batches = value != 0; return CGPT_OK; }
+    if (k == "trace_batches") { g_trace_batches = value != 0; return CGPT_OK; }
     if (k == "gemm_grid") {
         if (value < 0 || (value & 7)) return cgpt_fail(CGPT_ERR_INVALID, "cgpt_set_option: gemm_grid must be 0 (one workgroup per CU) or a positive multiple of 8");
         g_gemm_grid = value;

@@ -248,7 +248,9 @@ cgpt_status cgpt_profile_batches(cgpt_handle h, int32_t* samples_out, int64_t ca
  *   "gemm_grid":   0 (default) = one workgroup of the persistent 256x256 GEMM per CU; n > 0 (a multiple of 8) = at most n workgroups, i.e.
  *                  CUs left free for kernels of another stream (tools/two_stream_probe.py; measured: no split beats the default).
  *   "sync_batches": MEASUREMENT aid; 1 = cgpt_sample_counts* wait for the stream after every classifier batch (a --pmc profiler keeps a
- *                  record per in-flight dispatch and one call can enqueue tens of thousands); 0 (default) = nothing is synchronised.
+ *                  record per in-flight dispatch and one call can enqueue tens of thousands: profiles/r06/pmc_sigsegv.txt); 0 (default) =
+ *                  nothing is synchronised.  It stays in the shipped library on purpose: counters must be taken on the binary that ships.
+ *   "trace_batches": MEASUREMENT aid; 1 = one stderr line per classifier batch the cgpt_sample_counts* entry points enqueue; 0 (default).
  * (A lab build of the library -- make LAB=1, never shipped -- additionally accepts the experimental schedules 2, 5..11, 15 and
  * timing-study switches that skip work; profiles/r01/gemm_variants.txt.) */
 cgpt_status cgpt_set_option(const char* key, int32_t value);
