@@ -85,6 +85,10 @@ template <int DPAD> __device__ __forceinline__ int k_chunk_pos(int row, int ch) 
 #ifndef CGPT_ATT_PLAIN_WALK
 #define CGPT_ATT_PLAIN_WALK 0       // A/B builds: 1 = the round-robin (sample, head) walk of rounds 1-2
 #endif
+#ifndef CGPT_ATT_ABLATE
+#define CGPT_ATT_ABLATE 0           // timing studies of the streaming kernel ONLY (wrong results): 1 no exp, 2 V fragments of a chunk's first
+#endif                              // unit only, 4 K fragments not re-read, 8 one of twelve P.V MFMAs, 16 QK^T of a chunk's first units only,
+                                    // 32 requests for the block's first chunk only, 64 no maximum / rescale check, 128 no chunk barrier
 #ifndef CGPT_ATT_LONE_CARRIED
 #define CGPT_ATT_LONE_CARRIED 1     // A/B builds: 0 = rounds 2-5, a query block of its own for the lone query of Tq = 256 k + 1
 #endif
@@ -471,8 +475,12 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     constexpr bool FOLD = DPAD > HD;
     constexpr float RESCALE_LOG2 = 8.0f;
 
+    // Both buffers zero, once: rows past the end of the keys are never requested (see request_part), so a buffer row holds either
+    // what an earlier chunk left there or these zeros -- finite either way, and the keys' P is 0.  Then the
     // pad slots of both buffers, once: K chunks >= DC are zero (q is zero there too, but 0 x stale-LDS NaN would not be), V chunk DC
     // holds the ones column (DPAD > HD), the rest of a V row's tail is zero
+    for (int sidx = tid; sidx < 2 * STAGE / 8; sidx += 512) *reinterpret_cast<f16x8*>(smem + sidx * 8) = zero8;
+    __syncthreads();
     for (int sidx = tid; sidx < 2 * TKP * (KC - DC + VC - DC); sidx += 512) {
         const int buf = sidx / (TKP * (KC - DC + VC - DC)), rem = sidx % (TKP * (KC - DC + VC - DC));
         const int row = rem / (KC - DC + VC - DC), k = rem % (KC - DC + VC - DC);
@@ -507,36 +515,44 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
     // request chunk c of work item w into buffer `buf`: request r = wave + 8 i of the chunk covers slots 64 r .. 64 r + 63 of
     // the buffer image (K slots first); a lane fetches the 16-byte chunk that belongs in ITS slot, pad slots are skipped.
     // The slot -> (row, source chunk) decode does not depend on the chunk: one packed register per request, made once.
+    // What a request costs is instructions, not bytes (round 6: requests for the block's first chunk only = -13 % of the kernel; a
+    // request was ~25 instructions -- row clamp, 64-bit address arithmetic, lane masks reloaded from spilled SGPRs).  Now a lane's
+    // byte offset inside the pair's K (or V) rows is made once per kernel, 0xffffffff where the lane has nothing to fetch (pad slot,
+    // row beyond a balanced chunk, request beyond the image); per chunk there are two scalar bases and ONE scalar limit -- the bytes
+    // of the chunk's rows that exist -- and a request is compare, mask, global_load_lds (scalar base + 32-bit lane offset), unmask.
     constexpr int NI = (NREQ + 7) / 8, KREQ = KSLOTS / 64;
-    int rowch[NI];                                                          // row << 8 | source chunk (>= DC: pad slot, no request)
+    unsigned voff[NI];
+    unsigned from_v = 0;                                                    // bit i: request i of this wave fetches V (wave-uniform)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int r = wave + 8 * i, slot = r * 64 + lane;
-        if (r < KREQ) { const int row = slot / KC; rowch[i] = row << 8 | k_chunk_pos<DPAD>(row, slot - row * KC); }   // the swizzle is an involution
-        else { const int sv = slot - KSLOTS, row = sv / VC; rowch[i] = row << 8 | (sv - row * VC); }
+        int row, ch;
+        if (r < KREQ) { row = slot / KC; ch = k_chunk_pos<DPAD>(row, slot - row * KC); }   // the swizzle is an involution
+        else { const int sv = slot - KSLOTS; row = sv / VC; ch = sv - row * VC; from_v |= 1u << i; }
+        voff[i] = (r < NREQ && ch < DC && row < CK) ? (unsigned)(row * (int)p.ldk + ch * 8) * 2u : 0xffffffffu;
     }
+    from_v = __builtin_amdgcn_readfirstlane(from_v);
     // The requests of a chunk are issued inside the first two units of the previous chunk (request i in unit i % 2): issued in one
     // burst after the barrier, the workgroup's 78 KiB went through the CU's one address unit (64 B / clock) with all eight waves
     // waiting for their turn -- 14 % of the kernel in the phase stamps; issued any later they have less time to land.
-    int nw = 0, nc = 0;                                                     // the chunk being requested: work item, chunk
-    const half_t *nKg = nullptr, *nVg = nullptr;
+    const char *nKb = nullptr, *nVb = nullptr;                              // the chunk being requested: first byte of its K rows / V rows
+    unsigned nlimit = 0;                                                    // ... and the bytes of its rows that exist (0: nothing to request)
     auto set_next = [&](int w, int c) {
-        nw = w; nc = c;
         const int pair = pair_of(w / nqb);
         const int h = pair % p.heads, b = pair / p.heads;
-        nKg = p.K + (int64_t)b * p.kv_batch_stride + h * HD;
-        nVg = p.V + (int64_t)b * p.kv_batch_stride + h * HD;
+        const int64_t first = (int64_t)b * p.kv_batch_stride + h * HD + (int64_t)c * CK * p.ldk;    // (elements; 32-bit offsets inside a sample: launch check)
+        nKb = reinterpret_cast<const char*>(p.K + first);
+        nVb = reinterpret_cast<const char*>(p.V + first);
+        const int rows = min(CK, p.Tk - c * CK);                           // rows past the end of the keys are not fetched
+        nlimit = w < nwork ? (unsigned)(rows * (int)p.ldk) * 2u : 0u;      // (past the last work item: nothing)
     };
-    auto request_part = [&](int i, int buf) {                               // request i of this wave for chunk (nw, nc) into buffer `buf`
-        const int r = wave + 8 * i;                                        // wave-uniform
-        if (r >= NREQ || nw >= nwork) return;
-        const int ch = rowch[i] & 255;
-        const int grow = min(nc * CK + (rowch[i] >> 8), p.Tk - 1);         // rows past the end: a valid row (its P is 0)
-        const half_t* src = (r < KREQ ? nKg : nVg) + (grow * (int)p.ldk + ch * 8);   // 32-bit offsets inside a sample (launch check)
-        half_t* dst = smem + buf * STAGE + r * 512;                        // 64 lanes x 8 halfs per request
-        if (ch < DC && (rowch[i] >> 8) < CK)                                // (rows of the buffer a balanced chunk does not use: no request)
+    auto request_part = [&](int i, int buf) {                               // request i of this wave for the chunk of set_next into buffer `buf`
+        if (voff[i] < nlimit) {                                             // (a lane's row exists <=> its offset is below the limit: ch * 16 < ldk * 2)
+            const char* src = (((from_v >> i) & 1) ? nVb : nKb) + voff[i];
+            char* dst = smem_raw + buf * (STAGE * 2) + (wave + 8 * i) * 1024;   // 64 lanes x 16 bytes per request
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
     };
     auto request_unit = [&](int u, int buf) {                               // the requests that belong to unit u of the current chunk
 #pragma unroll
@@ -627,7 +643,7 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             CGPT_S2STAMP(1)                              // waiting for this wave's requests of the chunk (and the item's Q)
-            __syncthreads();
+            if (!(CGPT_ATT_ABLATE & 128) || c == 0) __syncthreads();
             CGPT_S2STAMP(2)                              // barrier
             if (carrier && c == 0) {
                 // this wave's partial softmax of the lone query: O^T column 0, maximum -inf, denominator 0.  (Its own LDS words, read and
@@ -687,13 +703,14 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                 f16x4 vr[NDT][2];
                 {
                     // (one address register per chunk; unit, key half and d-tile are instruction offsets)
+                    if (!(CGPT_ATT_ABLATE & 2) || u == 0)
                     static_for<NDT>([&](auto dtc) __attribute__((always_inline)) {
                         constexpr int dt = decltype(dtc)::value;
                         vr[dt][0] = lds_read_tr16_untracked<(u * 32 * VSTR + dt * 16) * 2>(vlane);
                         vr[dt][1] = lds_read_tr16_untracked<(u * 32 * VSTR + 16 * VSTR + dt * 16) * 2>(vlane);
                     });
                 }
-                request_unit(u, buf ^ 1);
+                if (!(CGPT_ATT_ABLATE & 32) || c == 0) request_unit(u, buf ^ 1);
                 // QK^T of the NEXT unit goes to the matrix pipe first ...
                 // (unconditionally inside the chunk: a conditional fragment read makes the compiler split the fp16 vectors into
                 // halves and re-pack them with v_perm in front of every MFMA; units past the end read valid LDS and are never used)
@@ -701,8 +718,8 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                 // the other path, waits for ALL LDS reads -- the uncounted V reads included -- after the first K fragment read; a short
                 // last chunk pays 12 MFMAs on valid, unused LDS contents once per block)
                 if (u + 1 < UPC) {
-                    qk(sc[(u + 1) & 1], kf);
-                    if (u + 2 < UPC) read_k(kf, u + 2);
+                    if (!(CGPT_ATT_ABLATE & 16) || u == 0) qk(sc[(u + 1) & 1], kf);
+                    if (u + 2 < UPC && !(CGPT_ATT_ABLATE & 4)) read_k(kf, u + 2);
                 }
                 // ... and this unit's softmax runs under it
                 const int kb = key0 + u * 32;
@@ -736,7 +753,7 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                 if constexpr (FOLD) {
                     // scores are (q . k) scale log2 e - reference already
                     const bool first = c == 0 && u == 0;                   // wave-uniform: no reference yet (it is 0, o is 0)
-                    if (first || __builtin_amdgcn_ballot_w64(mx[0] > RESCALE_LOG2 || mx[1] > RESCALE_LOG2) != 0) {
+                    if (first || (!(CGPT_ATT_ABLATE & 64) && __builtin_amdgcn_ballot_w64(mx[0] > RESCALE_LOG2 || mx[1] > RESCALE_LOG2) != 0)) {
                         const bool nxt = u + 1 < UPC && u + 1 < nu;        // the next unit's scores exist and carry the old reference
                         mx[0] = max_over_lane_groups(mx[0]);
                         mx[1] = max_over_lane_groups(mx[1]);
@@ -765,7 +782,7 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
 #pragma unroll
                         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) e[kt * 4 + r] = __builtin_amdgcn_exp2f(s_cur[t][kt][r]);
+                            for (int r = 0; r < 4; ++r) e[kt * 4 + r] = (CGPT_ATT_ABLATE & 1) ? s_cur[t][kt][r] : __builtin_amdgcn_exp2f(s_cur[t][kt][r]);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) pf[t][j] = (half_t)e[j];
                     }
@@ -808,7 +825,8 @@ __global__ __launch_bounds__(512) void attention_stream_kernel(AttnParams p) {
                 for (int dt = 0; dt < NDT; ++dt) {
                     const f16x8 vf = __builtin_shufflevector(vr[dt][0], vr[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t], o[t][dt], 0, 0, 0);
+                    for (int t = 0; t < 2; ++t)
+                        if (!(CGPT_ATT_ABLATE & 8) || (dt == 0 && t == 0)) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t], o[t][dt], 0, 0, 0);
                 }
                 return true;
             });
