@@ -193,7 +193,11 @@ def test_streaming_attention_rising_scores_rescale_path(hd):
 
 
 @pytest.mark.parametrize("hd,Tq,Tk,B,heads", [(88, 1025, 1025, 2, 3), (88, 257, 577, 3, 2), (64, 513, 1025, 2, 2), (88, 1, 1025, 9, 2),
-                                              (64, 257, 289, 1, 1), (88, 1025, 353, 1, 2)])
+                                              (64, 257, 289, 1, 1), (88, 1025, 353, 1, 2),
+                                              # more work items than workgroups: a workgroup meets carrying and plain blocks in turn (the
+                                              # rotation), rewrites the lone query's LDS state and Q fragment item after item -- 384 items of
+                                              # four blocks per pair; 320 items that ALL carry (one block per pair); 66 samples: the walk by samples
+                                              (88, 1025, 1025, 24, 4), (88, 257, 577, 40, 8), (64, 513, 400, 66, 3)])
 def test_streaming_attention_lone_query_is_split_by_keys(hd, Tq, Tk, B, heads):
     """Tq = 256 k + 1 (the CLS token on a 16 n x 16 n patch grid; T = 1025 at the reference's image size, minigpt4.py:32): the last query
     block of the streaming kernel holds one query, whose keys are split over the eight waves by 32-key unit and merged through LDS.
@@ -224,7 +228,11 @@ def test_streaming_attention_lone_query_is_split_by_keys(hd, Tq, Tk, B, heads):
         qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
         od = torch.full((B, Tq, D), float("nan"), device=DEV, dtype=torch.float16)
         _lib.check(L.cgpt_attention_f16(P(qd), D, P(kd), P(vd), D, P(od), D, B, heads, hd, Tq, Tk, scale, stream()))
+        # a second launch must give the same BITS: the partial softmaxes meet in LDS behind barriers, a race would show as a difference
+        od2 = torch.full((B, Tq, D), float("nan"), device=DEV, dtype=torch.float16)
+        _lib.check(L.cgpt_attention_f16(P(qd), D, P(kd), P(vd), D, P(od2), D, B, heads, hd, Tq, Tk, scale, stream()))
         torch.cuda.synchronize()
+        assert torch.equal(od, od2), f"two launches differ ({case}, d{hd} {Tq}x{Tk}, B{B} h{heads})"
         ref = attn_ref(q, k, v, heads, hd, scale)
         got = od.cpu().float()
         report(f"streaming attention, lone query ({case}) d{hd} {Tq}x{Tk}: the lone row", got[:, Tq - 1], ref[:, Tq - 1], 6e-3)
