@@ -48,8 +48,8 @@ __device__ __forceinline__ f16x4 lds_read_tr16(const half_t* p) {
 // rounds 2-5 the V reads of a chunk's units 1 and 2 each waited until the requests for the NEXT chunk -- issued one unit earlier, into
 // the other buffer -- had landed (two memory latencies per chunk and wave; plain ds_read_b128 carry alias information and get no such
 // wait).  The kernel's own counted waits and chunk barriers are what orders requests and reads.  The compiler does not count these
-// reads in lgkmcnt either: lds_wait() in front of their first use; its own counted waits stay safe (LDS returns in order, uncounted
-// reads only make a wait longer).
+// reads in lgkmcnt either: an `s_waitcnt lgkmcnt(0)` tied to their registers stands in front of their first use; the compiler's own
+// counted waits stay safe (LDS returns in order, uncounted reads only make a wait longer).
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression (instruction offsets)
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NT) void attention_kernel(AttnParams p) {
 //     compute streams the pair's K and V at the latency of one 78-KB chunk in flight (profiles/r06/attention_stream_lone_query.txt).
 //     Now the pair's LAST FULL block carries it: at the end of every chunk, with the chunk still in LDS, wave (unit % 8) runs the lone
 //     query against ONE 32-key unit -- a 16-column tile whose columns all hold that query -- as an online softmax of its own whose
-//     state (O^T column, maximum, denominator: DPAD + 2 floats per wave) lives in LDS between chunks (no registers to spare: 238 of
+//     state (O^T column, maximum, denominator: DPAD + 4 floats per wave) lives in LDS between chunks (no registers to spare: 238 of
 //     256); the eight partial softmaxes are merged after the block's last chunk.  No extra K / V traffic, four work items per pair,
 //     and the block that carries the query rotates over a workgroup's items (32 workgroups per XCD would otherwise pin it).
 // Work order: the query blocks of one (sample, head) re-read the same K and V (360 KB at T = 1025).  Workgroups are dealt to the 8
