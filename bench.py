@@ -137,8 +137,8 @@ def cpu_baseline_and_parity(clf, x, process_group=None):
     ViT-G of oracle/model_oracle.py: the restatement of the reference's smoothing.py:29-56 + eva_vit.py, same weights --
     downloaded from the device -- same image, and the GPU's own noise draws, exported), and (b) run on the GPU through the
     product path.  Returns (cpu_baseline, parity): the timed CPU figure scaled to the headline unit, and the comparison of the
-    two results (label, abstain, radius, per-sample argmax agreement).  process_group: in a multi-rank run the group that holds rank 0
-    alone, so that the GPU side of this leg draws all its samples here and ends in no collective (the other ranks are waiting)."""
+    two results (label, abstain, radius, per-sample argmax agreement).  process_group: `certifiedgpt_amd.LOCAL_ONLY` in a multi-rank run,
+    so that the GPU side of this leg draws all its samples here and ends in no collective (the other ranks are waiting)."""
     import numpy as np
     import certifiedgpt_amd as cg
     from oracle import model_oracle as mo, smooth_oracle as so
@@ -266,9 +266,8 @@ def main():
         assert dist.get_world_size() == args.gpus and dist.get_backend() == backend
     else:
         torch.cuda.set_device(local)
-    # a group that holds rank 0 alone (every rank must take part in making it): rank 0's CPU / parity leg draws all of its samples
-    # on its own GPU and ends in no collective while the other ranks wait at the final barrier
-    solo = dist.new_group(ranks=[0]) if world > 1 else None
+    # rank 0's CPU / parity leg draws all of its samples on its own GPU and ends in no collective while the other ranks wait at the
+    # final barrier: a Smooth that is told to stay local (no new process group: nothing here that an 8-GPU run executes for the first time)
 
     import certifiedgpt_amd as cg
     if os.environ.get("CGPT_GEMM_KERNEL"):          # A/B measurements only; default = the library's own choice
@@ -675,7 +674,7 @@ def main():
             line["roofline"]["flop_per_launch"] = fc1_flops / max(fc1_n, 1)
         if not args.no_cpu_baseline and headline:
             try:
-                cb, line["parity"] = cpu_baseline_and_parity(clf, images[0], process_group=solo)
+                cb, line["parity"] = cpu_baseline_and_parity(clf, images[0], process_group=cg.LOCAL_ONLY if world > 1 else None)
                 line["cpu_baseline"] = cb
                 # the like-for-like leg: the headline config itself on the oracle, when it fits the budget (single rank only: at N > 1
                 # the other ranks are waiting at the barrier below)

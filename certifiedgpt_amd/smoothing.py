@@ -22,7 +22,21 @@ import torch
 from . import _lib
 
 
+class _LocalOnly:
+    """`Smooth(..., process_group=LOCAL_ONLY)`: this object draws ALL of its samples on this rank and never enters a collective, whatever
+    process group the process is in -- one rank of a multi-rank job can certify on its own while the others do something else (bench.py:
+    rank 0's CPU / parity leg).  No torch.distributed call is made for it (in particular no `new_group`, which every rank would have to enter)."""
+
+    def __repr__(self):
+        return "LOCAL_ONLY"
+
+
+LOCAL_ONLY = _LocalOnly()
+
+
 def _world(group):
+    if group is LOCAL_ONLY:
+        return 0, 1
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
@@ -64,6 +78,8 @@ class Smooth(object):
                logits (e.g. full MiniGPT-4 + label adapter on PyTorch-ROCm): then only noise and vote run in HIP.
         :param num_classes, sigma: as smoothing.py:19-27
         :param seed: key of the counter-based noise stream; sample indices never repeat within one Smooth object
+        :param process_group: the torch.distributed group whose ranks share every `_sample_noise` (default: the world); `LOCAL_ONLY`: none --
+               all samples on this rank, no collective, even inside an initialised multi-rank job
         :param device_stats: finish certify / predict on the GPU (cgpt_certify_device / cgpt_predict_device: wavefront
                arg-max, Clopper-Pearson bound, binomial test, Phi^-1 in float64) and copy back 16 bytes instead of the
                histograms; same float64 code as the host path.  Applies to `certify` and `predict`; `certify_many` finishes its
@@ -124,7 +140,7 @@ class Smooth(object):
         """Does this `_sample_noise` end in the collective?  Always with more than one rank; with one rank only on request."""
         if world > 1:
             return True
-        if not self.force_collective:
+        if not self.force_collective or self.process_group is LOCAL_ONLY:
             return False
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized()

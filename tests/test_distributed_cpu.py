@@ -374,3 +374,45 @@ def test_eight_gpu_batch_plan_is_the_shapes_of_design_section_6():
     assert bench.planned_batches(1, 0, 60, 100, 100, 255, 51)[0] == [255] * 40 + [255] * 7 + [15]
     # ragged shares (N = 1000 over 8 GPUs is 125 + 13/12 of n0 = 100) and the one-image call
     assert cg.batch_plan(1, 138, 200) == [138] and cg.batch_plan(3, 138, 200) == [200, 200, 14] and cg.batch_plan(0, 5, 8) == []
+
+
+def _local_only_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = None
+        if rank == 0:                                     # rank 1 does NOT take part: a collective here would hang until the timeout
+            eng = ImagesEngine()
+            s = cg.Smooth(eng, K, 0.5, seed=11, process_group=cg.LOCAL_ONLY, force_collective=True)
+            xs = torch.zeros(3, 3, 8, 8)
+            out = (s.certify(xs[0], 51, 77, 0.01, 16), int(s.predict(xs[0], 125, 0.001, 32)), s.certify_many(xs, 51, 77, 0.01, 16),
+                   s.certify_images(xs, 51, 77, 0.01, 16), eng.calls[:2])
+        dist.barrier()                                    # both ranks meet again only here
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_local_only_smooth_never_enters_a_collective_inside_a_multi_rank_job():
+    """bench.py at N > 1: rank 0 runs its CPU / parity leg through `Smooth(..., process_group=LOCAL_ONLY)` while the other ranks wait at
+    the final barrier.  In a two-rank gloo job rank 0 alone certifies / predicts / certifies groups of images with such an object -- all
+    draws on rank 0 (the engine is asked for the WHOLE ranges), no all-reduce even with force_collective -- and gets what a
+    single-process Smooth gets; rank 1 goes straight to the barrier."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_local_only_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    eng = ImagesEngine()
+    s = cg.Smooth(eng, K, 0.5, seed=11)
+    xs = torch.zeros(3, 3, 8, 8)
+    want = (s.certify(xs[0], 51, 77, 0.01, 16), int(s.predict(xs[0], 125, 0.001, 32)), s.certify_many(xs, 51, 77, 0.01, 16),
+            s.certify_images(xs, 51, 77, 0.01, 16), eng.calls[:2])
+    assert got[1] is None and got[0] == want
+    assert want[4][0][:2] == (0, 51) and want[4][1][:2] == (51, 77)      # whole ranges: nothing was sharded away
+    assert repr(cg.LOCAL_ONLY) == "LOCAL_ONLY"
